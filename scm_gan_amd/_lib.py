@@ -1,0 +1,69 @@
+"""ctypes binding of libscmgan_hip.so (the C ABI declared in include/scm_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing or a
+call fails, this module raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libscmgan_hip.so")
+
+PAD_ZERO, PAD_CIRCULAR = 0, 1
+ACT_NONE, ACT_LRELU, ACT_SIGMOID = 0, 1, 2
+
+c_float_p = ctypes.c_void_p  # raw device pointers travel as void*
+
+
+class ConvDesc(ctypes.Structure):
+    """Mirror of scm_conv3x3_desc (include/scm_hip.h)."""
+    _fields_ = [
+        ("x1", ctypes.c_void_p), ("x2", ctypes.c_void_p), ("c1", ctypes.c_int32), ("c2", ctypes.c_int32),
+        ("gate1", ctypes.c_void_p), ("gate2", ctypes.c_void_p), ("gate_act", ctypes.c_int32),
+        ("wpack", ctypes.c_void_p),
+        ("cout", ctypes.c_int32),
+        ("scale", ctypes.c_void_p),
+        ("bias", ctypes.c_void_p),
+        ("sbias", ctypes.c_void_p),
+        ("y1", ctypes.c_void_p), ("y2", ctypes.c_void_p), ("co1", ctypes.c_int32),
+        ("B", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32),
+        ("pad_mode", ctypes.c_int32), ("act", ctypes.c_int32),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raise loudly when absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "scm_gan_amd: %s not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        L.scm_version.restype = ctypes.c_int
+        L.scm_last_error.restype = ctypes.c_char_p
+        L.scm_conv3x3_pack_floats.restype = ctypes.c_size_t
+        L.scm_conv3x3_pack_floats.argtypes = [ctypes.c_int, ctypes.c_int]
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed (%d): %s" % (what, rc, lib().scm_last_error().decode()))
+
+
+def ptr(t):
+    """Device pointer of a contiguous fp32 torch tensor (or None)."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "scm_gan_amd ops need contiguous tensors"
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

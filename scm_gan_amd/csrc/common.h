@@ -1,0 +1,48 @@
+// Shared helpers for libscmgan_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/scm_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// thread-local error slot, defined in api.cpp
+void scm_set_error(const char* fmt, ...);
+int scm_check_hip(hipError_t e, const char* what);
+
+#define SCM_REQUIRE(cond, ...)                 \
+    do {                                       \
+        if (!(cond)) {                         \
+            scm_set_error(__VA_ARGS__);        \
+            return SCM_EINVAL;                 \
+        }                                      \
+    } while (0)
+
+#define SCM_LAUNCH_CHECK(what)                             \
+    do {                                                   \
+        int _rc = scm_check_hip(hipGetLastError(), what);  \
+        if (_rc) return _rc;                               \
+    } while (0)
+
+__device__ __forceinline__ float scm_act(float v, int act) {
+    if (act == SCM_ACT_LRELU) return v > 0.f ? v : 0.01f * v;
+    if (act == SCM_ACT_SIGMOID) return 1.f / (1.f + expf(-v));
+    return v;
+}
+
+// derivative of the activation expressed through the saved OUTPUT y = act(x)
+// (leaky_relu keeps the sign of x; sigmoid' = y(1-y)).
+__device__ __forceinline__ float scm_act_grad_from_out(float y, int act) {
+    if (act == SCM_ACT_LRELU) return y > 0.f ? 1.f : 0.01f;
+    if (act == SCM_ACT_SIGMOID) return y * (1.f - y);
+    return 1.f;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}

@@ -1,0 +1,338 @@
+// 3x3 stride-1 same-size convolution as an implicit GEMM on the fp32 MFMA pipe
+// (v_mfma_f32_32x32x2_f32), NCHW in / NCHW out, zero or circular halo.
+//
+// Replaces (reference /root/reference): nn.Conv2d / nn.ConvTranspose2d forward
+// and input-gradient at models.py:76-102 (Transition), :145-155 (Encoder),
+// :274-278 (Decoder).
+//
+// GEMM view per image b:   D[co][p] = sum_{ci,tap} Wc[co][ci][tap] * Xpad[ci][p + tap]
+//   MFMA A operand = weights  (lane -> co, k -> ci)   read from LDS as one vector
+//   MFMA B operand = pixels   (lane -> p,  k -> ci)   read from the LDS halo tile
+//   D: lane&31 -> pixel, so every accumulator register stores 2 x 128 B rows
+//   of the NCHW output.
+//
+// Workgroup = 4 waves = NP = 128*PT consecutive pixels (flattened y*W+x) of one
+// image x one group of CT*32 output channels.  Wave w owns pixels
+// [w*32*PT, (w+1)*32*PT) and all CT*32 couts: CT*PT accumulator tiles.
+// K loop: chunks of KC=8 input channels; per chunk the halo tile
+// [KC][rows+2][W+2] and the weight slab [KC][9][32][CT] are staged in LDS; the
+// im2col is only an address offset (ky*(W+2)+kx) into the halo tile.
+#include "common.h"
+
+#define KC 8
+#define MAXJ 8
+
+struct ConvKArgs {
+    const float* x1; const float* x2; int c1; int c2;
+    const float* gate1; const float* gate2; int gate_act;
+    const float* wpack; int cout;
+    const float* scale; const float* bias; const float* sbias;
+    float* y1; float* y2; int co1;
+    int B; int H; int W;
+    int pad_mode; int act;
+    int tiles_per_img; int plane;
+};
+
+template <int CT, int PT>
+__global__ void __launch_bounds__(256, 2) conv3x3_mfma_kernel(const ConvKArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int CW = CT * 32;
+    constexpr int WCHUNK = KC * 9 * CW;
+    constexpr int NPW = PT * 32, NP = 4 * NPW;
+    constexpr int TAP_UNROLL = CT == 4 ? 9 : 1;
+    float* wl = smem;
+    float* xl = smem + WCHUNK;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int W = a.W, H = a.H, HW = H * W;
+    const int ROWPL = W + 2;
+    const int PLANE = a.plane;
+
+    const int b = blockIdx.x / a.tiles_per_img;
+    const int tile = blockIdx.x - b * a.tiles_per_img;
+    const int cg = blockIdx.y;
+    const int p0 = tile * NP;
+    const int r0 = p0 / W;
+    int plast = p0 + NP;
+    if (plast > HW) plast = HW;
+    const int nrows = (plast - 1) / W - r0 + 3;
+    const int nelem = nrows * ROWPL;
+
+    // staging map: LDS element e = tid + 256*j  <-  plane offset goff[j]
+    // (-1: zero fill, -2: not mine)
+    int goff[MAXJ];
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+        const int e = tid + 256 * j;
+        int g = -2;
+        if (e < nelem) {
+            const int r = e / ROWPL;
+            const int c = e - r * ROWPL;
+            int iy = r0 - 1 + r, ix = c - 1;
+            if (a.pad_mode == SCM_PAD_CIRCULAR) {
+                iy = iy < 0 ? iy + H : (iy >= H ? iy - H : iy);
+                ix = ix < 0 ? ix + W : (ix >= W ? ix - W : ix);
+                g = iy * W + ix;
+            } else {
+                g = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? iy * W + ix : -1;
+            }
+        }
+        goff[j] = g;
+    }
+
+    int baddr[PT];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        int p = p0 + wave * NPW + pt * 32 + l31;
+        if (p > HW - 1) p = HW - 1;
+        const int y = p / W;
+        const int x = p - y * W;
+        baddr[pt] = lh * PLANE + (y - r0) * ROWPL + x;
+    }
+
+    f32x16 acc[CT][PT];
+#pragma unroll
+    for (int m = 0; m < CT; ++m)
+#pragma unroll
+        for (int n = 0; n < PT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    const int cin = a.c1 + a.c2;
+    const float* wsrc = a.wpack + (size_t)cg * cin * 9 * CW;
+    const int gate_act = a.gate_act;
+
+    for (int ci0 = 0; ci0 < cin; ci0 += KC) {
+        // ---- stage weights: contiguous [KC][9][32][CT] slab
+        {
+            const f32x4* src4 = reinterpret_cast<const f32x4*>(wsrc + (size_t)ci0 * 9 * CW);
+            f32x4* dst4 = reinterpret_cast<f32x4*>(wl);
+            constexpr int PER_CI4 = 9 * CW / 4;
+#pragma unroll
+            for (int k = 0; k < (WCHUNK / 4 + 255) / 256; ++k) {
+                const int i = tid + 256 * k;
+                if (i < WCHUNK / 4) {
+                    const int cil = i / PER_CI4;
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (ci0 + cil < cin) v = src4[i];
+                    dst4[i] = v;
+                }
+            }
+        }
+        // ---- stage halo tile of KC input planes
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            const int ci = ci0 + c;
+            const float* src = nullptr;
+            const float* gsrc = nullptr;
+            if (ci < cin) {
+                if (ci < a.c1) {
+                    const size_t o = ((size_t)b * a.c1 + ci) * HW;
+                    src = a.x1 + o;
+                    if (gate_act) gsrc = a.gate1 + o;
+                } else {
+                    const size_t o = ((size_t)b * a.c2 + (ci - a.c1)) * HW;
+                    src = a.x2 + o;
+                    if (gate_act) gsrc = a.gate2 + o;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < MAXJ; ++j) {
+                const int g = goff[j];
+                if (g != -2) {
+                    float v = 0.f;
+                    if (src != nullptr && g >= 0) {
+                        v = src[g];
+                        if (gate_act) v *= scm_act_grad_from_out(gsrc[g], gate_act);
+                    }
+                    xl[c * PLANE + tid + 256 * j] = v;
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- MFMA over the chunk: 9 taps x KC/2 k-steps
+#pragma unroll TAP_UNROLL
+        for (int tap = 0; tap < 9; ++tap) {
+            const int toff = (tap / 3) * ROWPL + (tap % 3);
+#pragma unroll
+            for (int ks = 0; ks < KC / 2; ++ks) {
+                const float* wp = wl + ((2 * ks + lh) * 9 + tap) * CW + l31 * CT;
+                float av[CT];
+                if constexpr (CT == 4) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(wp);
+                    av[0] = t[0]; av[1] = t[1]; av[2] = t[2]; av[3] = t[3];
+                } else if constexpr (CT == 2) {
+                    const f32x2 t = *reinterpret_cast<const f32x2*>(wp);
+                    av[0] = t[0]; av[1] = t[1];
+                } else {
+                    av[0] = wp[0];
+                }
+                float bv[PT];
+#pragma unroll
+                for (int n = 0; n < PT; ++n) bv[n] = xl[baddr[n] + 2 * ks * PLANE + toff];
+#pragma unroll
+                for (int m = 0; m < CT; ++m)
+#pragma unroll
+                    for (int n = 0; n < PT; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[n], acc[m][n], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: scale, bias, per-sample bias, activation, NCHW store
+    const float sc = a.scale ? *a.scale : 1.f;
+    const int co2n = a.cout - a.co1;
+#pragma unroll
+    for (int m = 0; m < CT; ++m) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = cg * CW + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (co < a.cout) {
+                float add = 0.f;
+                if (a.bias) add += a.bias[co];
+                if (a.sbias) add += a.sbias[(size_t)b * a.cout + co];
+                float* dst = co < a.co1 ? a.y1 + ((size_t)b * a.co1 + co) * HW
+                                        : a.y2 + ((size_t)b * co2n + (co - a.co1)) * HW;
+#pragma unroll
+                for (int n = 0; n < PT; ++n) {
+                    const int p = p0 + wave * NPW + n * 32 + l31;
+                    if (p < HW) dst[p] = scm_act(acc[m][n][r] * sc + add, a.act);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ pack
+__global__ void pack_conv3x3_kernel(const float* __restrict__ w, int cin, int cout, int transposed_src,
+                                    float* __restrict__ fwd, float* __restrict__ dgr) {
+    // element accessor of the equivalent conv weight Wc[co][ci][t]
+    auto Wc = [&](int co, int ci, int t) -> float {
+        return transposed_src ? w[((size_t)ci * cout + co) * 9 + (8 - t)] : w[((size_t)co * cin + ci) * 9 + t];
+    };
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (fwd) {
+        const int ct = cout <= 32 ? 1 : (cout <= 64 ? 2 : 4);
+        const int cw = ct * 32;
+        const int ng = (cout + cw - 1) / cw;
+        const int total = ng * cin * 9 * cw;
+        if (idx < total) {
+            int e = idx;
+            const int t = e % ct; e /= ct;
+            const int l = e % 32; e /= 32;
+            const int tap = e % 9; e /= 9;
+            const int ci = e % cin; e /= cin;
+            const int g = e;
+            const int co = g * cw + t * 32 + l;
+            fwd[idx] = co < cout ? Wc(co, ci, tap) : 0.f;
+        }
+    }
+    if (dgr) {
+        // dgrad conv: input channels = cout, output channels = cin, taps flipped
+        const int ct = cin <= 32 ? 1 : (cin <= 64 ? 2 : 4);
+        const int cw = ct * 32;
+        const int ng = (cin + cw - 1) / cw;
+        const int total = ng * cout * 9 * cw;
+        if (idx < total) {
+            int e = idx;
+            const int t = e % ct; e /= ct;
+            const int l = e % 32; e /= 32;
+            const int tap = e % 9; e /= 9;
+            const int co = e % cout; e /= cout;
+            const int g = e;
+            const int ci = g * cw + t * 32 + l;
+            dgr[idx] = ci < cin ? Wc(co, ci, 8 - tap) : 0.f;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ host
+static inline int conv_ct(int cout) { return cout <= 32 ? 1 : (cout <= 64 ? 2 : 4); }
+
+extern "C" size_t scm_conv3x3_pack_floats(int cin, int cout) {
+    if (cin <= 0 || cout <= 0) return 0;
+    const int cw = conv_ct(cout) * 32;
+    const int ng = (cout + cw - 1) / cw;
+    return (size_t)ng * cin * 9 * cw;
+}
+
+extern "C" int scm_pack_conv3x3_weights(const float* w, int cin, int cout, int transposed_src,
+                                        float* fwd_pack, float* dgrad_pack, void* stream) {
+    SCM_REQUIRE(w && cin > 0 && cout > 0, "scm_pack_conv3x3_weights: bad arguments (cin=%d cout=%d)", cin, cout);
+    SCM_REQUIRE(fwd_pack || dgrad_pack, "scm_pack_conv3x3_weights: no output requested");
+    size_t n = 0;
+    if (fwd_pack) n = scm_conv3x3_pack_floats(cin, cout);
+    if (dgrad_pack) {
+        const size_t m = scm_conv3x3_pack_floats(cout, cin);
+        if (m > n) n = m;
+    }
+    const int threads = 256;
+    const int blocks = (int)((n + threads - 1) / threads);
+    hipLaunchKernelGGL(pack_conv3x3_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, w, cin, cout,
+                       transposed_src, fwd_pack, dgrad_pack);
+    SCM_LAUNCH_CHECK("pack_conv3x3_kernel");
+    return SCM_OK;
+}
+
+template <int CT, int PT>
+static int launch_conv(const ConvKArgs& k, int groups, hipStream_t s) {
+    constexpr int NP = 128 * PT;
+    ConvKArgs a = k;
+    const int HW = a.H * a.W;
+    a.tiles_per_img = (HW + NP - 1) / NP;
+    int rows = (NP % a.W == 0) ? NP / a.W : (NP + a.W - 2) / a.W + 1;
+    if (rows > a.H) rows = a.H;
+    a.plane = (rows + 2) * (a.W + 2);
+    if (a.plane > MAXJ * 256) {
+        scm_set_error("scm_conv3x3: image width %d too large for the halo staging map", a.W);
+        return SCM_EUNSUPPORTED;
+    }
+    const size_t lds = ((size_t)KC * 9 * CT * 32 + (size_t)KC * a.plane) * sizeof(float);
+    auto kern = conv3x3_mfma_kernel<CT, PT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        int rc = scm_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+                               "hipFuncSetAttribute");
+        if (rc) return rc;
+        attr_set = true;
+    }
+    dim3 grid(a.B * a.tiles_per_img, groups);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+    SCM_LAUNCH_CHECK("conv3x3_mfma_kernel");
+    return SCM_OK;
+}
+
+extern "C" int scm_conv3x3(const scm_conv3x3_desc* d, void* stream) {
+    SCM_REQUIRE(d != nullptr, "scm_conv3x3: null descriptor");
+    SCM_REQUIRE(d->x1 && d->c1 > 0, "scm_conv3x3: x1/c1 required");
+    SCM_REQUIRE((d->x2 != nullptr) == (d->c2 > 0) && d->c2 >= 0, "scm_conv3x3: x2/c2 mismatch");
+    SCM_REQUIRE(d->wpack && d->cout > 0, "scm_conv3x3: wpack/cout required");
+    SCM_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0, "scm_conv3x3: bad shape B=%d H=%d W=%d", d->B, d->H, d->W);
+    SCM_REQUIRE(d->y1 && d->co1 > 0 && d->co1 <= d->cout, "scm_conv3x3: y1/co1 invalid");
+    SCM_REQUIRE((d->co1 == d->cout) || d->y2, "scm_conv3x3: y2 required when co1 < cout");
+    SCM_REQUIRE(d->pad_mode == SCM_PAD_ZERO || d->pad_mode == SCM_PAD_CIRCULAR, "scm_conv3x3: bad pad_mode %d",
+                d->pad_mode);
+    SCM_REQUIRE(d->act >= 0 && d->act <= 2 && d->gate_act >= 0 && d->gate_act <= 2, "scm_conv3x3: bad act");
+    if (d->gate_act) {
+        SCM_REQUIRE(d->gate1 && (d->c2 == 0 || d->gate2), "scm_conv3x3: gate tensors required with gate_act");
+    }
+    ConvKArgs k;
+    k.x1 = d->x1; k.x2 = d->x2; k.c1 = d->c1; k.c2 = d->c2;
+    k.gate1 = d->gate1; k.gate2 = d->gate2; k.gate_act = d->gate_act;
+    k.wpack = d->wpack; k.cout = d->cout;
+    k.scale = d->scale; k.bias = d->bias; k.sbias = d->sbias;
+    k.y1 = d->y1; k.y2 = d->y2; k.co1 = d->co1;
+    k.B = d->B; k.H = d->H; k.W = d->W; k.pad_mode = d->pad_mode; k.act = d->act;
+    k.tiles_per_img = 0; k.plane = 0;
+    const int ct = conv_ct(d->cout);
+    const int groups = (d->cout + ct * 32 - 1) / (ct * 32);
+    hipStream_t s = (hipStream_t)stream;
+    if (ct == 4) return launch_conv<4, 2>(k, groups, s);
+    if (ct == 2) return launch_conv<2, 4>(k, groups, s);
+    return launch_conv<1, 4>(k, groups, s);
+}
