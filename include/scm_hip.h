@@ -95,6 +95,33 @@ size_t scm_conv3x3_pack_floats(int cin, int cout);
 int scm_pack_conv3x3_weights(const float* w, int cin, int cout, int transposed_src,
                              float* fwd_pack, float* dgrad_pack, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Weight / bias gradient of the same convolution (autograd backward of
+ * nn.Conv2d / nn.ConvTranspose2d triggered by main.py:285).
+ *
+ *   dyp = dy * act'(gate)            (gate = saved forward output, optional)
+ *   dw[co][ci][ky][kx] (=|+=) sum_{b,y,x} dyp[b,co,y,x] * inpad[b,ci,y+ky-1,x+kx-1]
+ *   csum[b][co]        =  sum_{y,x} dyp[b,co,y,x]          (optional)
+ *   db[co]             (=|+=) sum_b csum[b][co]            (optional)
+ * `in` is concat(x1, x2) as in scm_conv3x3.  transposed_dst = 1 writes the
+ * nn.ConvTranspose2d layout dw[ci][co][2-ky][2-kx].  accumulate = 1 adds into
+ * dw / db instead of overwriting.  part_ws / csum_ws are caller-provided
+ * workspaces sized by scm_conv3x3_wgrad_workspace (split-K partial slabs,
+ * reduced in a fixed order: results are bitwise reproducible).
+ * ---------------------------------------------------------------------- */
+typedef struct scm_conv3x3_wgrad_desc {
+    const float* x1; const float* x2; int32_t c1; int32_t c2;
+    const float* dy; const float* gate; int32_t gate_act; int32_t cout;
+    float* dw; float* db; float* csum;
+    float* part_ws; float* csum_ws;
+    int32_t B; int32_t H; int32_t W; int32_t pad_mode;
+    int32_t transposed_dst; int32_t accumulate;
+} scm_conv3x3_wgrad_desc;
+
+int scm_conv3x3_wgrad_workspace(int B, int H, int W, int cin, int cout, size_t* part_floats,
+                                size_t* csum_floats);
+int scm_conv3x3_wgrad(const scm_conv3x3_wgrad_desc* d, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -31,6 +31,18 @@ class ConvDesc(ctypes.Structure):
     ]
 
 
+class WgradDesc(ctypes.Structure):
+    """Mirror of scm_conv3x3_wgrad_desc (include/scm_hip.h)."""
+    _fields_ = [
+        ("x1", ctypes.c_void_p), ("x2", ctypes.c_void_p), ("c1", ctypes.c_int32), ("c2", ctypes.c_int32),
+        ("dy", ctypes.c_void_p), ("gate", ctypes.c_void_p), ("gate_act", ctypes.c_int32), ("cout", ctypes.c_int32),
+        ("dw", ctypes.c_void_p), ("db", ctypes.c_void_p), ("csum", ctypes.c_void_p),
+        ("part_ws", ctypes.c_void_p), ("csum_ws", ctypes.c_void_p),
+        ("B", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32), ("pad_mode", ctypes.c_int32),
+        ("transposed_dst", ctypes.c_int32), ("accumulate", ctypes.c_int32),
+    ]
+
+
 _lib = None
 
 

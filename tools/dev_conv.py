@@ -80,3 +80,45 @@ for (B, c1, c2, cout, H, W) in [(64, 128, 0, 128, 64, 64), (64, 128, 128, 128, 6
     torch.cuda.synchronize(); dt = (time.time() - t0) / n
     fl = 2.0 * B * H * W * cout * (c1 + c2) * 9
     print('time', (B, c1, c2, cout, H, W), '%.3f ms  %.1f TFLOP/s' % (dt * 1e3, fl / dt / 1e12))
+
+# ---------------- wgrad
+def wgrad(x1, x2, dy, gate, gate_act, pad, transposed=False):
+    B, c1, H, W = x1.shape; c2 = 0 if x2 is None else x2.shape[1]; cout = dy.shape[1]; cin = c1 + c2
+    pf = ctypes.c_size_t(); cf = ctypes.c_size_t()
+    L.check(lib.scm_conv3x3_wgrad_workspace(B, H, W, cin, cout, ctypes.byref(pf), ctypes.byref(cf)), 'ws')
+    part = torch.empty(pf.value, device=dev); cs = torch.empty(cf.value, device=dev)
+    dw = torch.empty((cin, cout, 3, 3) if transposed else (cout, cin, 3, 3), device=dev)
+    db = torch.empty(cout, device=dev); csum = torch.empty(B, cout, device=dev)
+    d = L.WgradDesc(L.ptr(x1), L.ptr(x2), c1, c2, L.ptr(dy), L.ptr(gate), gate_act, cout, L.ptr(dw), L.ptr(db), L.ptr(csum),
+                    L.ptr(part), L.ptr(cs), B, H, W, pad, int(transposed), 0)
+    L.check(lib.scm_conv3x3_wgrad(ctypes.byref(d), L.stream_ptr()), 'wgrad')
+    return dw, db, csum
+
+ok = True
+for (B, c1, c2, cout, H, W, pad, act) in [
+    (2, 16, 0, 128, 16, 16, 1, 1), (2, 128, 128, 128, 16, 16, 1, 1), (2, 9, 0, 128, 16, 16, 0, 1),
+    (2, 128, 0, 16, 16, 16, 0, 2), (2, 128, 128, 16, 16, 16, 1, 2), (1, 16, 0, 64, 20, 12, 0, 1),
+    (3, 64, 0, 48, 20, 13, 0, 0), (1, 128, 0, 128, 64, 64, 1, 1), (1, 21, 0, 128, 84, 84, 1, 1),
+    (2, 40, 0, 70, 9, 7, 1, 1), (1, 128, 0, 128, 128, 128, 0, 1)]:
+    x1 = torch.randn(B, c1, H, W); x2 = torch.randn(B, c2, H, W) if c2 else None
+    w = (torch.randn(cout, c1 + c2, 3, 3) * 0.05).double().requires_grad_(True); bb = torch.randn(cout).double().requires_grad_(True)
+    xin = (x1 if x2 is None else torch.cat([x1, x2], 1)).double()
+    y = ref_conv(xin, w, bb, pad, act)
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    dw, db, csum = wgrad(x1.to(dev), None if x2 is None else x2.to(dev), dy.float().to(dev), y.detach().float().to(dev), act, pad)
+    e1 = (dw.cpu() - w.grad.float()).abs().max().item() / max(1.0, w.grad.abs().max().item())
+    e2 = (db.cpu() - bb.grad.float()).abs().max().item() / max(1.0, bb.grad.abs().max().item())
+    e3 = (csum.sum(0).cpu() - bb.grad.float()).abs().max().item() / max(1.0, bb.grad.abs().max().item())
+    print('wgrad', (B, c1, c2, cout, H, W, pad, act), 'rel err dw %.2e db %.2e csum %.2e' % (e1, e2, e3))
+    ok &= e1 < 1e-4 and e2 < 1e-4 and e3 < 1e-4
+print('WGRAD ALL OK' if ok else 'WGRAD FAILED')
+for (B, c1, c2, cout, H, W) in [(64, 128, 0, 128, 64, 64), (64, 128, 128, 128, 64, 64), (64, 128, 128, 16, 64, 64), (64, 16, 0, 128, 64, 64)]:
+    x1 = torch.randn(B, c1, H, W, device=dev); x2 = torch.randn(B, c2, H, W, device=dev) if c2 else None
+    dy = torch.randn(B, cout, H, W, device=dev); g = torch.randn(B, cout, H, W, device=dev)
+    for _ in range(2): wgrad(x1, x2, dy, g, 1, 1)
+    torch.cuda.synchronize(); t0 = time.time(); n = 5
+    for _ in range(n): wgrad(x1, x2, dy, g, 1, 1)
+    torch.cuda.synchronize(); dt = (time.time() - t0) / n
+    fl = 2.0 * B * H * W * cout * (c1 + c2) * 9
+    print('wgrad time', (B, c1, c2, cout, H, W), '%.3f ms  %.1f TFLOP/s' % (dt * 1e3, fl / dt / 1e12))
