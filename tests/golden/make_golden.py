@@ -115,6 +115,20 @@ def npy(t):
     return t.detach().cpu().numpy().copy()
 
 
+class Fixture(dict):
+    """dict of arrays; tensors above `limit` elements are stored as a digest
+    (weights.digest: 3 moments + a 4096-point strided sample) under key#digest."""
+    limit = 70000
+
+    def __setitem__(self, key, value):
+        a = np.asarray(value)
+        if a.size > self.limit and a.dtype.kind == "f":
+            dict.__setitem__(self, key + "#digest", WS.digest(a, 4096))
+            dict.__setitem__(self, key + "#shape", np.array(a.shape, np.int64))
+        else:
+            dict.__setitem__(self, key, a)
+
+
 def grads_of(module):
     return {k: npy(p.grad) for k, p in module.named_parameters() if p.grad is not None}
 
@@ -128,7 +142,7 @@ def gen_modules(out, H, W, B, seed, with_grads=True, tag=""):
     import models
     rng = np.random.default_rng(1000 + seed)
     A, R, C, L = 5, 2, 3, 16
-    fx = {}
+    fx = Fixture()
 
     # ---- Encoder (models.py:123-157)
     enc = models.Encoder(L, C)
@@ -231,7 +245,7 @@ def gen_operators(out, seed):
     from coordconv import CoordConv2d
     from spatial_recurrent import CSRN
     rng = np.random.default_rng(3000 + seed)
-    fx = {}
+    fx = Fixture()
 
     # ---- SpectralNorm (spectral_normalization.py:14-68): three calls
     st = WS.transition_state(seed)
