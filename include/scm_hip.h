@@ -89,10 +89,13 @@ size_t scm_conv3x3_pack_floats(int cin, int cout);
  *              equivalent conv: taps flipped)                   when transposed_src == 1
  *   fwd_pack : pack for y = conv(x, w)          (scm_conv3x3_pack_floats(cin, cout) floats) or NULL
  *   dgrad_pack : pack for dx = conv(dy, w^T flipped) (scm_conv3x3_pack_floats(cout, cin) floats) or NULL
+ * Only input channels [w_ci0, w_ci0+cin) of a weight holding w_cin_total input
+ * channels are packed (w_cin_total = 0 means cin): Transition.conv1 convolves the
+ * 16 latent channels and folds its action channels into scm_action_bias.
  * Pack layout: [group g][ci][tap][32 lanes][CT] with cout = g*32*CT + t*32 + lane
  * at element t, CT = min(4, ceil(cout/32)); missing couts are zero.
  */
-int scm_pack_conv3x3_weights(const float* w, int cin, int cout, int transposed_src,
+int scm_pack_conv3x3_weights(const float* w, int cin, int cout, int transposed_src, int w_cin_total, int w_ci0,
                              float* fwd_pack, float* dgrad_pack, void* stream);
 
 /* ------------------------------------------------------------------------
@@ -116,11 +119,113 @@ typedef struct scm_conv3x3_wgrad_desc {
     float* part_ws; float* csum_ws;
     int32_t B; int32_t H; int32_t W; int32_t pad_mode;
     int32_t transposed_dst; int32_t accumulate;
+    int32_t dw_cin_total; int32_t dw_ci0;   /* dw holds dw_cin_total input channels (0 = c1+c2); write slice at dw_ci0 */
 } scm_conv3x3_wgrad_desc;
 
 int scm_conv3x3_wgrad_workspace(int B, int H, int W, int cin, int cout, size_t* part_floats,
                                 size_t* csum_floats);
 int scm_conv3x3_wgrad(const scm_conv3x3_wgrad_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Spectral normalisation (spectral_normalization.py:14-68).
+ *
+ * scm_sn_power_iter runs `steps` consecutive SpectralNorm._update_u_v calls
+ * (power_iterations = 1 each, :23-35) for up to 8 layers in one launch:
+ *   v <- W^T u / (|W^T u| + 1e-12);  u <- W v / (|W v| + 1e-12);  sigma = u.(W v)
+ * with W = w_bar viewed as [rows][cols]. u and v are updated IN PLACE (the
+ * reference rebinds u.data / v.data); sigma[k] / inv_sigma[k] (either may be
+ * NULL) receive the value after call k.
+ *
+ * scm_sn_fold_grad maps g = dL/d(W_bar/sigma) to the gradient of W_bar:
+ *   dw_bar (=|+=) g * inv_sigma - (<g, W_bar> * inv_sigma^2) * u v^T
+ * u and v are read at call time: the reference's autograd graph holds the live
+ * u/v parameters, so its backward sees the latest power-iteration state for
+ * every earlier forward call (oracle/scm_oracle.py sn_weight).
+ * ---------------------------------------------------------------------- */
+typedef struct scm_sn_layer {
+    const float* w_bar; float* u; float* v; float* sigma; float* inv_sigma;
+    int32_t rows; int32_t cols;
+} scm_sn_layer;
+
+int scm_sn_power_iter(int nlayers, const scm_sn_layer* layers, int steps, void* stream);
+int scm_sn_fold_grad(const float* g, const float* w_bar, const float* u, const float* v, const float* inv_sigma,
+                     int rows, int cols, int accumulate, float* dw_bar, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Generic small Conv2d (square kernel K, stride, zero padding `pad`), direct
+ * form on the vector ALU: RewardPredictor (models.py:230-239), Discriminator
+ * (models.py:199-219), CoordConv2d's inner conv (coordconv.py:8,15).
+ *   fwd:  y = act( conv(x, w) * (*scale) + bias )
+ *   bwd:  dyp = dy * act'(gate);  dx = scale * conv^T(dyp, w);
+ *         dw (=|+=) corr(x, dyp)  [w.r.t. the effective weight w*scale -> caller
+ *         folds scale];  db (=|+=) sum dyp
+ * ---------------------------------------------------------------------- */
+typedef struct scm_conv2d_desc {
+    const float* x; const float* w; const float* bias; const float* scale; float* y;
+    const float* gate; int32_t gate_act;
+    int32_t B; int32_t cin; int32_t H; int32_t W; int32_t cout;
+    int32_t K; int32_t stride; int32_t pad; int32_t act;
+} scm_conv2d_desc;
+
+int scm_conv2d_fwd(const scm_conv2d_desc* d, void* stream);
+int scm_conv2d_bwd(const scm_conv2d_desc* d, const float* dy, float* dx, float* dw, float* db, int accumulate,
+                   void* stream);
+
+/* ------------------------------------------------------------------------
+ * Bandwidth-bound pieces.
+ * ---------------------------------------------------------------------- */
+/* DifferentiableBernoulliSampler forward / eval threshold (models.py:30-40,
+ * 107-113). mode 0: out = (p > 0.5); mode 1: out = (noise < p); mode 2:
+ * out = (philox4x32(seed, offset + i/4) < p). Backward is the identity. */
+int scm_bernoulli(const float* p, const float* noise, float* out, size_t n, int mode, uint64_t seed,
+                  uint64_t offset, void* stream);
+
+/* Decoder factor sum x.view(B,L,C,H,W).sum(1) (models.py:280-287) and its
+ * backward (broadcast over L). */
+int scm_factor_sum(const float* x, float* y, int B, int L, int C, int HW, void* stream);
+int scm_factor_bcast(const float* dy, float* dx, int B, int L, int C, int HW, void* stream);
+
+/* per_sample[b] = mean over n = C*H*W of loss(sigmoid(logit), target).
+ * kind 0: F.binary_cross_entropy with the log clamp at -100 (main.py:189-190,
+ * 310-312); kind 1: squared error (main.py:814-816). prob (optional) receives
+ * sigmoid(logit).  _bwd: dlogit = g[b] * d per_sample[b] / d logit. */
+int scm_pixel_loss(const float* logit, const float* target, int B, int n, int kind, float* per_sample, float* prob,
+                   void* stream);
+int scm_pixel_loss_bwd(const float* logit, const float* target, const float* g, int B, int n, int kind,
+                       float* dlogit, void* stream);
+
+/* RewardPredictor tail (models.py:241-250): x[B][3][R][hw] -> softmax over the 3
+ * classes -> p0 - p2 -> map[B][R][hw] (optional) and r[B][R] = sum over hw. */
+int scm_reward_tail(const float* x, int B, int R, int hw, float* r_out, float* map_out, void* stream);
+int scm_reward_tail_bwd(const float* x, const float* g_r, const float* g_map, int B, int R, int hw, float* dx,
+                        void* stream);
+
+/* Action planes of Transition.conv1 (models.py:68-76) folded into a per-sample
+ * bias: sbias[b][co] = scale * sum_a act[b][a] * sum_tap w[co][c0+a][tap], w being
+ * the full [cout][cin][3][3] weight.  _bwd takes csum[b][co] = d sbias and emits
+ * d_act[B][A] and the action-channel slice of dw_eff (same layout as w). */
+int scm_action_bias(const float* act, const float* w, const float* scale, int B, int A, int cout, int cin, int c0,
+                    float* sbias, void* stream);
+int scm_action_bias_bwd(const float* act, const float* w, const float* scale, const float* csum, int B, int A,
+                        int cout, int cin, int c0, float* d_act, float* dw_eff, void* stream);
+
+/* y = act(x w^T + bias): Discriminator.fc1 + leaky_relu (models.py:205,221-222). */
+int scm_linear(const float* x, const float* w, const float* bias, int B, int nin, int nout, int act, float* y,
+               void* stream);
+int scm_linear_bwd(const float* x, const float* w, const float* y, const float* gy, int B, int nin, int nout, int act,
+                   float* dx, float* dw, float* db, void* stream);
+
+/* CoordConv2d input: out[B][C+2][H][W] = cat(x, coord_x, coord_y) (coordconv.py:12-14). */
+int scm_coord_cat(const float* x, float* out, int B, int C, int H, int W, void* stream);
+
+/* clip_grad_value_(clip_value) + Adam step for `count` tensors (main.py:125-129,
+ * 287-296). grads are first multiplied by grad_scale (1/world_size after a sum
+ * all-reduce), clamped to [-clip, clip] when clip_value > 0 (stored back, as
+ * clip_grad_value_ does), then m, v, p are updated with bias correction for
+ * `step` (1-based). Pointer tables are HOST arrays of device pointers. */
+int scm_adam_clip_multi(int count, float* const* params, float* const* grads, float* const* exp_avg,
+                        float* const* exp_avg_sq, const int* numel, float lr, float beta1, float beta2, float eps,
+                        int step, float clip_value, float grad_scale, void* stream);
 
 #ifdef __cplusplus
 }

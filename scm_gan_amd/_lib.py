@@ -40,7 +40,24 @@ class WgradDesc(ctypes.Structure):
         ("part_ws", ctypes.c_void_p), ("csum_ws", ctypes.c_void_p),
         ("B", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32), ("pad_mode", ctypes.c_int32),
         ("transposed_dst", ctypes.c_int32), ("accumulate", ctypes.c_int32),
+        ("dw_cin_total", ctypes.c_int32), ("dw_ci0", ctypes.c_int32),
     ]
+
+
+class SnLayer(ctypes.Structure):
+    """Mirror of scm_sn_layer."""
+    _fields_ = [("w_bar", ctypes.c_void_p), ("u", ctypes.c_void_p), ("v", ctypes.c_void_p),
+                ("sigma", ctypes.c_void_p), ("inv_sigma", ctypes.c_void_p),
+                ("rows", ctypes.c_int32), ("cols", ctypes.c_int32)]
+
+
+class Conv2dDesc(ctypes.Structure):
+    """Mirror of scm_conv2d_desc."""
+    _fields_ = [("x", ctypes.c_void_p), ("w", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("scale", ctypes.c_void_p),
+                ("y", ctypes.c_void_p), ("gate", ctypes.c_void_p), ("gate_act", ctypes.c_int32),
+                ("B", ctypes.c_int32), ("cin", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32),
+                ("cout", ctypes.c_int32), ("K", ctypes.c_int32), ("stride", ctypes.c_int32), ("pad", ctypes.c_int32),
+                ("act", ctypes.c_int32)]
 
 
 _lib = None
@@ -58,7 +75,38 @@ def lib():
         L.scm_version.restype = ctypes.c_int
         L.scm_last_error.restype = ctypes.c_char_p
         L.scm_conv3x3_pack_floats.restype = ctypes.c_size_t
-        L.scm_conv3x3_pack_floats.argtypes = [ctypes.c_int, ctypes.c_int]
+        vp, ci, cf, st = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+        u64 = ctypes.c_uint64
+        sigs = {
+            "scm_conv3x3_pack_floats": [ci, ci],
+            "scm_conv3x3": [vp, vp],
+            "scm_pack_conv3x3_weights": [vp, ci, ci, ci, ci, ci, vp, vp, vp],
+            "scm_conv3x3_wgrad_workspace": [ci, ci, ci, ci, ci, vp, vp],
+            "scm_conv3x3_wgrad": [vp, vp],
+            "scm_sn_power_iter": [ci, vp, ci, vp],
+            "scm_sn_fold_grad": [vp, vp, vp, vp, vp, ci, ci, ci, vp, vp],
+            "scm_conv2d_fwd": [vp, vp],
+            "scm_conv2d_bwd": [vp, vp, vp, vp, vp, ci, vp],
+            "scm_bernoulli": [vp, vp, vp, st, ci, u64, u64, vp],
+            "scm_factor_sum": [vp, vp, ci, ci, ci, ci, vp],
+            "scm_factor_bcast": [vp, vp, ci, ci, ci, ci, vp],
+            "scm_pixel_loss": [vp, vp, ci, ci, ci, vp, vp, vp],
+            "scm_pixel_loss_bwd": [vp, vp, vp, ci, ci, ci, vp, vp],
+            "scm_reward_tail": [vp, ci, ci, ci, vp, vp, vp],
+            "scm_reward_tail_bwd": [vp, vp, vp, ci, ci, ci, vp, vp],
+            "scm_action_bias": [vp, vp, vp, ci, ci, ci, ci, ci, vp, vp],
+            "scm_action_bias_bwd": [vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp, vp],
+            "scm_linear": [vp, vp, vp, ci, ci, ci, ci, vp, vp],
+            "scm_linear_bwd": [vp, vp, vp, vp, ci, ci, ci, ci, vp, vp, vp, vp],
+            "scm_coord_cat": [vp, vp, ci, ci, ci, ci, vp],
+            "scm_adam_clip_multi": [ci, vp, vp, vp, vp, vp, cf, cf, cf, cf, ci, cf, cf, vp],
+        }
+        for name, args in sigs.items():
+            fn = getattr(L, name)      # raises AttributeError when the library lacks a declared symbol
+            fn.argtypes = args
+            if name != "scm_conv3x3_pack_floats":
+                fn.restype = ctypes.c_int
+        L._scm_symbols = sorted(sigs) + ["scm_version", "scm_last_error"]
         _lib = L
     return _lib
 

@@ -209,10 +209,12 @@ __global__ void __launch_bounds__(256, 2) conv3x3_mfma_kernel(const ConvKArgs a)
 
 // ------------------------------------------------------------------ pack
 __global__ void pack_conv3x3_kernel(const float* __restrict__ w, int cin, int cout, int transposed_src,
-                                    float* __restrict__ fwd, float* __restrict__ dgr) {
-    // element accessor of the equivalent conv weight Wc[co][ci][t]
+                                    int wct, int wc0, float* __restrict__ fwd, float* __restrict__ dgr) {
+    // element accessor of the equivalent conv weight Wc[co][ci][t]; the stored
+    // tensor has wct input channels, of which [wc0, wc0+cin) are used
     auto Wc = [&](int co, int ci, int t) -> float {
-        return transposed_src ? w[((size_t)ci * cout + co) * 9 + (8 - t)] : w[((size_t)co * cin + ci) * 9 + t];
+        return transposed_src ? w[((size_t)(wc0 + ci) * cout + co) * 9 + (8 - t)]
+                              : w[((size_t)co * wct + wc0 + ci) * 9 + t];
     };
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (fwd) {
@@ -260,9 +262,11 @@ extern "C" size_t scm_conv3x3_pack_floats(int cin, int cout) {
     return (size_t)ng * cin * 9 * cw;
 }
 
-extern "C" int scm_pack_conv3x3_weights(const float* w, int cin, int cout, int transposed_src,
-                                        float* fwd_pack, float* dgrad_pack, void* stream) {
+extern "C" int scm_pack_conv3x3_weights(const float* w, int cin, int cout, int transposed_src, int w_cin_total,
+                                        int w_ci0, float* fwd_pack, float* dgrad_pack, void* stream) {
     SCM_REQUIRE(w && cin > 0 && cout > 0, "scm_pack_conv3x3_weights: bad arguments (cin=%d cout=%d)", cin, cout);
+    if (w_cin_total == 0) w_cin_total = cin;
+    SCM_REQUIRE(w_ci0 >= 0 && w_ci0 + cin <= w_cin_total, "scm_pack_conv3x3_weights: bad channel slice");
     SCM_REQUIRE(fwd_pack || dgrad_pack, "scm_pack_conv3x3_weights: no output requested");
     size_t n = 0;
     if (fwd_pack) n = scm_conv3x3_pack_floats(cin, cout);
@@ -273,7 +277,7 @@ extern "C" int scm_pack_conv3x3_weights(const float* w, int cin, int cout, int t
     const int threads = 256;
     const int blocks = (int)((n + threads - 1) / threads);
     hipLaunchKernelGGL(pack_conv3x3_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, w, cin, cout,
-                       transposed_src, fwd_pack, dgrad_pack);
+                       transposed_src, w_cin_total, w_ci0, fwd_pack, dgrad_pack);
     SCM_LAUNCH_CHECK("pack_conv3x3_kernel");
     return SCM_OK;
 }

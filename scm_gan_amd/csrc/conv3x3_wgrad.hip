@@ -149,7 +149,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wgrad_kernel(const WgradKArgs 
 //   dw[co][ci][3][3]                    (transposed_dst == 0, nn.Conv2d)
 //   dw[ci][co][3][3] with taps flipped  (transposed_dst == 1, nn.ConvTranspose2d)
 __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, int cout, int cin,
-                                    int transposed_dst, int accumulate, float* __restrict__ dw) {
+                                    int transposed_dst, int accumulate, int dct, int dc0, float* __restrict__ dw) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int per_tap = cout * cin;
     if (idx >= 9 * per_tap) return;
@@ -158,7 +158,8 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, 
     const int co = rem / cin, ci = rem - co * cin;
     float s = 0.f;
     for (int k = 0; k < nsplit; ++k) s += part[(size_t)k * 9 * per_tap + idx];
-    const size_t o = transposed_dst ? ((size_t)ci * cout + co) * 9 + (8 - t) : ((size_t)co * cin + ci) * 9 + t;
+    const size_t o = transposed_dst ? ((size_t)(dc0 + ci) * cout + co) * 9 + (8 - t)
+                                    : ((size_t)co * dct + dc0 + ci) * 9 + t;
     dw[o] = accumulate ? dw[o] + s : s;
 }
 
@@ -258,8 +259,10 @@ extern "C" int scm_conv3x3_wgrad(const scm_conv3x3_wgrad_desc* d, void* stream) 
     else rc = launch_wgrad<1, 4>(a, p, s);
     if (rc) return rc;
     const int total = 9 * d->cout * cin;
+    const int dct = d->dw_cin_total ? d->dw_cin_total : cin;
+    SCM_REQUIRE(d->dw_ci0 >= 0 && d->dw_ci0 + cin <= dct, "scm_conv3x3_wgrad: bad dw channel slice");
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, d->part_ws, p.nsplit, d->cout,
-                       cin, d->transposed_dst, d->accumulate, d->dw);
+                       cin, d->transposed_dst, d->accumulate, dct, d->dw_ci0, d->dw);
     SCM_LAUNCH_CHECK("wgrad_reduce_kernel");
     if (want_cs) {
         hipLaunchKernelGGL(csum_reduce_kernel, dim3((d->cout + 63) / 64), dim3(64), 0, s, d->csum_ws, d->B, p.spi,

@@ -1,0 +1,204 @@
+// Generic direct 2-D convolution (any square kernel, stride, zero padding) on the
+// vector ALU, for the small layers of the path that do not fit the 3x3 same-size
+// MFMA kernel: RewardPredictor conv1 (16->32, k3 s1 p0) and conv2 (32->3R, k3 s2
+// p0), models.py:230-232; Discriminator conv1-3 (k3 s2 p0), models.py:199-203;
+// CoordConv2d's arbitrary nn.Conv2d arguments, coordconv.py:8.  Together < 1 %
+// of the path's FLOPs (Dz).
+//
+// forward : thread = one output pixel x CB consecutive output channels
+// dgrad   : thread = one input pixel x CB consecutive input channels
+// wgrad   : workgroup = one (co, ci) pair, threads stride the (b, oy, ox) reduction
+#include "common.h"
+
+#define CB 8
+
+struct SmallConvArgs {
+    const float* x; const float* w; const float* bias; const float* scale; float* y;
+    const float* gate; int gate_act;
+    int B, cin, H, W, cout, OH, OW, K, stride, pad, act;
+};
+
+__global__ void __launch_bounds__(256) smallconv_fwd_kernel(const SmallConvArgs a) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int co0 = blockIdx.y * CB;
+    const int b = blockIdx.z;
+    if (p >= a.OH * a.OW) return;
+    const int oy = p / a.OW, ox = p - oy * a.OW;
+    float acc[CB];
+#pragma unroll
+    for (int k = 0; k < CB; ++k) acc[k] = 0.f;
+    const int KK = a.K * a.K;
+    for (int ci = 0; ci < a.cin; ++ci) {
+        const float* xp = a.x + ((size_t)b * a.cin + ci) * a.H * a.W;
+        for (int ky = 0; ky < a.K; ++ky) {
+            const int iy = oy * a.stride - a.pad + ky;
+            if (iy < 0 || iy >= a.H) continue;
+            for (int kx = 0; kx < a.K; ++kx) {
+                const int ix = ox * a.stride - a.pad + kx;
+                if (ix < 0 || ix >= a.W) continue;
+                const float xv = xp[iy * a.W + ix];
+#pragma unroll
+                for (int k = 0; k < CB; ++k) {
+                    const int co = co0 + k;
+                    if (co < a.cout) acc[k] = fmaf(a.w[((size_t)co * a.cin + ci) * KK + ky * a.K + kx], xv, acc[k]);
+                }
+            }
+        }
+    }
+    const float sc = a.scale ? *a.scale : 1.f;
+#pragma unroll
+    for (int k = 0; k < CB; ++k) {
+        const int co = co0 + k;
+        if (co < a.cout) {
+            const float v = acc[k] * sc + (a.bias ? a.bias[co] : 0.f);
+            a.y[((size_t)b * a.cout + co) * a.OH * a.OW + p] = scm_act(v, a.act);
+        }
+    }
+}
+
+// dx[b,ci,iy,ix] = scale * sum_{co,ky,kx} dyp[b,co,oy,ox] w[co,ci,ky,kx], oy*stride-pad+ky == iy
+__global__ void __launch_bounds__(256) smallconv_dgrad_kernel(const SmallConvArgs a, const float* __restrict__ dy,
+                                                              float* __restrict__ dx) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ci0 = blockIdx.y * CB;
+    const int b = blockIdx.z;
+    if (p >= a.H * a.W) return;
+    const int iy = p / a.W, ix = p - iy * a.W;
+    float acc[CB];
+#pragma unroll
+    for (int k = 0; k < CB; ++k) acc[k] = 0.f;
+    const int KK = a.K * a.K;
+    for (int ky = 0; ky < a.K; ++ky) {
+        const int ty = iy + a.pad - ky;
+        if (ty < 0 || ty % a.stride) continue;
+        const int oy = ty / a.stride;
+        if (oy >= a.OH) continue;
+        for (int kx = 0; kx < a.K; ++kx) {
+            const int tx = ix + a.pad - kx;
+            if (tx < 0 || tx % a.stride) continue;
+            const int ox = tx / a.stride;
+            if (ox >= a.OW) continue;
+            for (int co = 0; co < a.cout; ++co) {
+                const size_t o = ((size_t)b * a.cout + co) * a.OH * a.OW + oy * a.OW + ox;
+                float g = dy[o];
+                if (a.gate_act) g *= scm_act_grad_from_out(a.gate[o], a.gate_act);
+#pragma unroll
+                for (int k = 0; k < CB; ++k) {
+                    const int ci = ci0 + k;
+                    if (ci < a.cin) acc[k] = fmaf(a.w[((size_t)co * a.cin + ci) * KK + ky * a.K + kx], g, acc[k]);
+                }
+            }
+        }
+    }
+    const float sc = a.scale ? *a.scale : 1.f;
+#pragma unroll
+    for (int k = 0; k < CB; ++k) {
+        const int ci = ci0 + k;
+        if (ci < a.cin) dx[((size_t)b * a.cin + ci) * a.H * a.W + p] = acc[k] * sc;
+    }
+}
+
+// dw[co,ci,ky,kx] = sum_{b,oy,ox} dyp[b,co,oy,ox] x[b,ci,oy*s-pad+ky,ox*s-pad+kx];  db[co] = sum dyp
+#define SW_MAXKK 25
+__global__ void __launch_bounds__(256) smallconv_wgrad_kernel(const SmallConvArgs a, const float* __restrict__ dy,
+                                                              float* __restrict__ dw, float* __restrict__ db,
+                                                              int accumulate) {
+    __shared__ float red[4];
+    const int co = blockIdx.x, ci = blockIdx.y;
+    const int KK = a.K * a.K;
+    float acc[SW_MAXKK];
+#pragma unroll
+    for (int k = 0; k < SW_MAXKK; ++k) acc[k] = 0.f;
+    float bsum = 0.f;
+    const int OHW = a.OH * a.OW;
+    const int total = a.B * OHW;
+    for (int e = threadIdx.x; e < total; e += 256) {
+        const int b = e / OHW;
+        const int p = e - b * OHW;
+        const int oy = p / a.OW, ox = p - oy * a.OW;
+        const size_t o = ((size_t)b * a.cout + co) * OHW + p;
+        float g = dy[o];
+        if (a.gate_act) g *= scm_act_grad_from_out(a.gate[o], a.gate_act);
+        bsum += g;
+        const float* xp = a.x + ((size_t)b * a.cin + ci) * a.H * a.W;
+#pragma unroll
+        for (int k = 0; k < SW_MAXKK; ++k) {
+            if (k < KK) {
+                const int ky = k / a.K, kx = k - ky * a.K;
+                const int iy = oy * a.stride - a.pad + ky, ix = ox * a.stride - a.pad + kx;
+                if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) acc[k] = fmaf(g, xp[iy * a.W + ix], acc[k]);
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < SW_MAXKK; ++k) {
+        if (k < KK) {
+            float v = wave_sum(acc[k]);
+            __syncthreads();
+            if (lane == 0) red[wave] = v;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const float s = red[0] + red[1] + red[2] + red[3];
+                float* d = dw + ((size_t)co * a.cin + ci) * KK + k;
+                *d = accumulate ? *d + s : s;
+            }
+        }
+    }
+    if (db != nullptr && ci == 0) {
+        float v = wave_sum(bsum);
+        __syncthreads();
+        if (lane == 0) red[wave] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float s = red[0] + red[1] + red[2] + red[3];
+            db[co] = accumulate ? db[co] + s : s;
+        }
+    }
+}
+
+static int fill_args(const scm_conv2d_desc* d, SmallConvArgs* a, const char* who) {
+    SCM_REQUIRE(d != nullptr, "%s: null descriptor", who);
+    SCM_REQUIRE(d->B > 0 && d->cin > 0 && d->cout > 0 && d->H > 0 && d->W > 0, "%s: bad shape", who);
+    SCM_REQUIRE(d->K >= 1 && d->K * d->K <= SW_MAXKK && d->stride >= 1 && d->pad >= 0, "%s: bad K/stride/pad", who);
+    const int OH = (d->H + 2 * d->pad - d->K) / d->stride + 1, OW = (d->W + 2 * d->pad - d->K) / d->stride + 1;
+    SCM_REQUIRE(OH > 0 && OW > 0, "%s: empty output", who);
+    SCM_REQUIRE(d->act >= 0 && d->act <= 2 && d->gate_act >= 0 && d->gate_act <= 2, "%s: bad act", who);
+    a->x = d->x; a->w = d->w; a->bias = d->bias; a->scale = d->scale; a->y = d->y;
+    a->gate = d->gate; a->gate_act = d->gate_act;
+    a->B = d->B; a->cin = d->cin; a->H = d->H; a->W = d->W; a->cout = d->cout; a->OH = OH; a->OW = OW;
+    a->K = d->K; a->stride = d->stride; a->pad = d->pad; a->act = d->act;
+    return SCM_OK;
+}
+
+extern "C" int scm_conv2d_fwd(const scm_conv2d_desc* d, void* stream) {
+    SmallConvArgs a;
+    int rc = fill_args(d, &a, "scm_conv2d_fwd");
+    if (rc) return rc;
+    SCM_REQUIRE(d->x && d->w && d->y, "scm_conv2d_fwd: x, w, y required");
+    dim3 grid((a.OH * a.OW + 255) / 256, (a.cout + CB - 1) / CB, a.B);
+    hipLaunchKernelGGL(smallconv_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    SCM_LAUNCH_CHECK("smallconv_fwd_kernel");
+    return SCM_OK;
+}
+
+extern "C" int scm_conv2d_bwd(const scm_conv2d_desc* d, const float* dy, float* dx, float* dw, float* db,
+                              int accumulate, void* stream) {
+    SmallConvArgs a;
+    int rc = fill_args(d, &a, "scm_conv2d_bwd");
+    if (rc) return rc;
+    SCM_REQUIRE(dy && d->w, "scm_conv2d_bwd: dy and w required");
+    SCM_REQUIRE(!d->gate_act || d->gate, "scm_conv2d_bwd: gate tensor required");
+    if (dx) {
+        dim3 grid((a.H * a.W + 255) / 256, (a.cin + CB - 1) / CB, a.B);
+        hipLaunchKernelGGL(smallconv_dgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, a, dy, dx);
+        SCM_LAUNCH_CHECK("smallconv_dgrad_kernel");
+    }
+    if (dw) {
+        SCM_REQUIRE(d->x, "scm_conv2d_bwd: x required for dw");
+        dim3 grid(a.cout, a.cin);
+        hipLaunchKernelGGL(smallconv_wgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, a, dy, dw, db, accumulate);
+        SCM_LAUNCH_CHECK("smallconv_wgrad_kernel");
+    }
+    return SCM_OK;
+}

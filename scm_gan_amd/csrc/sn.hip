@@ -1,0 +1,147 @@
+// Spectral normalisation: power iteration and its gradient fold.
+// Replaces spectral_normalization.py:23-35 (SpectralNorm._update_u_v) and the
+// autograd backward through sigma = u . (W_bar v), W = W_bar / sigma.
+//
+// One workgroup of 1024 threads per layer (the matrices are 32..128 rows by
+// 27..2304 columns, 3 KB .. 1.2 MB): the two mat-vecs are latency-bound, not
+// bandwidth-bound, so the layer's whole iteration -- v <- normalise(W^T u),
+// u <- normalise(W v), sigma = u . (W v) -- runs in ONE launch, with
+// wavefront-shuffle (DPP) reductions; several layers share a launch
+// (blockIdx.x = layer).  u and v are updated in place in caller memory, as the
+// reference does with u.data / v.data.
+#include "common.h"
+
+#define SN_THREADS 1024
+#define SN_MAX_LAYERS 8
+
+struct SnLayer {
+    const float* w; float* u; float* v; float* sigma; float* inv_sigma;
+    int rows; int cols;
+};
+struct SnBatch {
+    SnLayer l[SN_MAX_LAYERS];
+    int steps;      // power-iteration calls to run back to back (>=1)
+};
+
+__device__ __forceinline__ float block_sum_1024(float v, float* red) {
+    // red: 16 floats of LDS
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float t = (lane < (SN_THREADS / 64)) ? red[lane] : 0.f;
+    t = wave_sum(t);
+    return t;
+}
+
+__global__ void __launch_bounds__(SN_THREADS) sn_power_iter_kernel(const SnBatch batch) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const SnLayer L = batch.l[blockIdx.x];
+    const int rows = L.rows, cols = L.cols;
+    float* us = smem;              // [rows]
+    float* vs = smem + rows;       // [cols]
+    float* ss = vs + cols;         // [rows]  W v
+    float* red = ss + rows;        // [16]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    for (int i = tid; i < rows; i += SN_THREADS) us[i] = L.u[i];
+    __syncthreads();
+    for (int step = 0; step < batch.steps; ++step) {
+        // ---- v = l2normalize(W^T u): thread j owns columns j, j+1024, ...
+        float part = 0.f;
+        for (int j = tid; j < cols; j += SN_THREADS) {
+            float acc = 0.f;
+            for (int r = 0; r < rows; ++r) acc = fmaf(L.w[(size_t)r * cols + j], us[r], acc);
+            vs[j] = acc;
+            part = fmaf(acc, acc, part);
+        }
+        float nrm = sqrtf(block_sum_1024(part, red));
+        float inv = 1.f / (nrm + 1e-12f);
+        for (int j = tid; j < cols; j += SN_THREADS) vs[j] *= inv;
+        __syncthreads();
+        // ---- s = W v: one wave per row, lanes stride the columns
+        for (int r = wave; r < rows; r += SN_THREADS / 64) {
+            float acc = 0.f;
+            for (int j = lane; j < cols; j += 64) acc = fmaf(L.w[(size_t)r * cols + j], vs[j], acc);
+            acc = wave_sum(acc);
+            if (lane == 0) ss[r] = acc;
+        }
+        __syncthreads();
+        part = 0.f;
+        for (int r = tid; r < rows; r += SN_THREADS) part = fmaf(ss[r], ss[r], part);
+        nrm = sqrtf(block_sum_1024(part, red));
+        inv = 1.f / (nrm + 1e-12f);
+        // ---- u = s / (|s| + eps); sigma = u . s
+        part = 0.f;
+        for (int r = tid; r < rows; r += SN_THREADS) {
+            const float un = ss[r] * inv;
+            us[r] = un;
+            part = fmaf(un, ss[r], part);
+        }
+        const float sigma = block_sum_1024(part, red);
+        if (tid == 0) {
+            if (L.sigma) L.sigma[step] = sigma;
+            if (L.inv_sigma) L.inv_sigma[step] = 1.f / sigma;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < rows; i += SN_THREADS) L.u[i] = us[i];
+    for (int j = tid; j < cols; j += SN_THREADS) L.v[j] = vs[j];
+}
+
+extern "C" int scm_sn_power_iter(int nlayers, const scm_sn_layer* layers, int steps, void* stream) {
+    SCM_REQUIRE(nlayers > 0 && nlayers <= SN_MAX_LAYERS && layers, "scm_sn_power_iter: 1..%d layers", SN_MAX_LAYERS);
+    SCM_REQUIRE(steps >= 1, "scm_sn_power_iter: steps >= 1");
+    SnBatch b;
+    size_t lds = 0;
+    for (int i = 0; i < nlayers; ++i) {
+        const scm_sn_layer& s = layers[i];
+        SCM_REQUIRE(s.w_bar && s.u && s.v && s.rows > 0 && s.cols > 0, "scm_sn_power_iter: layer %d invalid", i);
+        b.l[i].w = s.w_bar; b.l[i].u = s.u; b.l[i].v = s.v;
+        b.l[i].sigma = s.sigma; b.l[i].inv_sigma = s.inv_sigma;
+        b.l[i].rows = s.rows; b.l[i].cols = s.cols;
+        const size_t need = ((size_t)2 * s.rows + s.cols + 16) * sizeof(float);
+        if (need > lds) lds = need;
+    }
+    SCM_REQUIRE(lds <= 64 * 1024, "scm_sn_power_iter: matrix too large for the LDS vectors");
+    b.steps = steps;
+    hipLaunchKernelGGL(sn_power_iter_kernel, dim3(nlayers), dim3(SN_THREADS), lds, (hipStream_t)stream, b);
+    SCM_LAUNCH_CHECK("sn_power_iter_kernel");
+    return SCM_OK;
+}
+
+// ---------------------------------------------------------------- backward
+// Given g = dL/dW_eff (gradient w.r.t. the normalised weight W_bar/sigma):
+//   dwbar (=|+=) g * inv_sigma - (<g, W_bar> * inv_sigma^2) * u v^T
+// u, v are read NOW (the reference's saved u/v alias the live parameters, so
+// its backward sees the latest power-iteration state; oracle sn_weight()).
+__global__ void __launch_bounds__(SN_THREADS) sn_fold_kernel(const float* __restrict__ g,
+                                                             const float* __restrict__ wbar,
+                                                             const float* __restrict__ u,
+                                                             const float* __restrict__ v,
+                                                             const float* __restrict__ inv_sigma, int rows, int cols,
+                                                             int accumulate, float* __restrict__ dwbar) {
+    __shared__ float red[16];
+    const int n = rows * cols;
+    float part = 0.f;
+    for (int i = threadIdx.x; i < n; i += SN_THREADS) part = fmaf(g[i], wbar[i], part);
+    const float dot = block_sum_1024(part, red);
+    const float is = *inv_sigma;
+    const float c = dot * is * is;
+    for (int i = threadIdx.x; i < n; i += SN_THREADS) {
+        const int r = i / cols, j = i - r * cols;
+        const float val = g[i] * is - c * u[r] * v[j];
+        dwbar[i] = accumulate ? dwbar[i] + val : val;
+    }
+}
+
+extern "C" int scm_sn_fold_grad(const float* g, const float* w_bar, const float* u, const float* v,
+                                const float* inv_sigma, int rows, int cols, int accumulate, float* dw_bar,
+                                void* stream) {
+    SCM_REQUIRE(g && w_bar && u && v && inv_sigma && dw_bar && rows > 0 && cols > 0, "scm_sn_fold_grad: bad arguments");
+    hipLaunchKernelGGL(sn_fold_kernel, dim3(1), dim3(SN_THREADS), 0, (hipStream_t)stream, g, w_bar, u, v, inv_sigma,
+                       rows, cols, accumulate, dw_bar);
+    SCM_LAUNCH_CHECK("sn_fold_kernel");
+    return SCM_OK;
+}

@@ -1,0 +1,116 @@
+"""Layer modules backed by the HIP operators (scm_gan_amd.ops).
+
+They keep torch's parameter names, shapes and default initialisation so the
+reference's state_dicts load unchanged, but their forward never calls a torch
+compute op.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+def _pair(v):
+    return v[0] if isinstance(v, (tuple, list)) else v
+
+
+class Conv2d(nn.Module):
+    """nn.Conv2d(in, out, kernel_size, stride, padding, padding_mode) look-alike.
+
+    3x3 / stride 1 / padding 1 (zero or circular) runs on the MFMA implicit-GEMM
+    kernel; any other geometry (RewardPredictor, Discriminator, CoordConv2d
+    arguments) on the direct kernel.  `padding=2, padding_mode='circular'` is
+    accepted and means one wrapped pixel per side, the torch<=1.4 behaviour the
+    reference was written against (models.py:51-56).
+    """
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, padding_mode="zeros", bias=True):
+        super().__init__()
+        k, s, p = _pair(kernel_size), _pair(stride), _pair(padding)
+        if padding_mode == "circular":
+            if not (k == 3 and s == 1 and p in (1, 2)):
+                raise ValueError("circular padding is implemented for the 3x3 stride-1 same-size conv only")
+            p = 1
+        elif padding_mode != "zeros":
+            raise ValueError("unsupported padding_mode %r" % padding_mode)
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding, self.padding_mode = k, s, p, padding_mode
+        ref = nn.Conv2d(in_channels, out_channels, k, stride=s, padding=p, bias=bias)   # torch default init
+        self.weight = nn.Parameter(ref.weight.detach().clone())
+        self.bias = nn.Parameter(ref.bias.detach().clone()) if bias else None
+        self._pack_key = None
+        self._packs = None
+
+    @property
+    def is_mfma(self):
+        return self.kernel_size == 3 and self.stride == 1 and self.padding == 1
+
+    def _get_packs(self, w, cin_conv):
+        key = (w.data_ptr(), w._version, ops.weights_epoch(), cin_conv, w.device)
+        if self._pack_key != key:
+            self._packs = ops.pack_conv3x3(w, cin_conv, self.out_channels, False, self.in_channels, 0)
+            self._pack_key = key
+        return self._packs
+
+    def forward(self, x, x2=None, act_vec=None, act=ops.ACT_NONE, _sn=None):
+        """x (and optionally x2, concatenated along channels without being
+        materialised); act_vec: (B, A) values of A trailing constant input planes
+        (circular 3x3 only).  _sn = (weight_bar, u, v, inv_sigma) from SpectralNorm."""
+        if _sn is not None:
+            w, u, v, inv_sigma = _sn
+        else:
+            w, u, v, inv_sigma = self.weight, None, None, None
+        if self.is_mfma:
+            cin_conv = x.shape[1] + (0 if x2 is None else x2.shape[1])
+            if act_vec is not None and self.padding_mode != "circular":
+                raise ValueError("constant action planes fold into a bias only under circular padding")
+            cfg = {"pad": ops.PAD_CIRCULAR if self.padding_mode == "circular" else ops.PAD_ZERO, "act": act,
+                   "transposed": False, "packs": self._get_packs(w, cin_conv)}
+            return ops.Conv3x3Fn.apply(x, x2, act_vec, w, self.bias, inv_sigma, u, v, cfg)
+        if x2 is not None or act_vec is not None:
+            raise ValueError("two-input / action-plane forms need the 3x3 same-size geometry")
+        return ops.Conv2dFn.apply(x, w, self.bias, inv_sigma, u, v, self.kernel_size, self.stride, self.padding, act)
+
+    def extra_repr(self):
+        return "{in_channels}, {out_channels}, kernel_size={kernel_size}, stride={stride}, padding={padding}, " \
+               "padding_mode={padding_mode}".format(**self.__dict__)
+
+
+class ConvTranspose3x3(nn.Module):
+    """nn.ConvTranspose2d(in, out, (3,3), stride=1, padding=1) (models.py:260-266):
+    weight layout (in, out, 3, 3); computed as the equivalent zero-padded conv with
+    channel-transposed, tap-flipped weights on the MFMA kernel."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        ref = nn.ConvTranspose2d(in_channels, out_channels, (3, 3), stride=1, padding=1)
+        self.weight = nn.Parameter(ref.weight.detach().clone())
+        self.bias = nn.Parameter(ref.bias.detach().clone())
+        self._pack_key = None
+        self._packs = None
+
+    def forward(self, x, act=ops.ACT_NONE):
+        w = self.weight
+        key = (w.data_ptr(), w._version, ops.weights_epoch(), w.device)
+        if self._pack_key != key:
+            self._packs = ops.pack_conv3x3(w, self.in_channels, self.out_channels, True, self.in_channels, 0)
+            self._pack_key = key
+        cfg = {"pad": ops.PAD_ZERO, "act": act, "transposed": True, "packs": self._packs}
+        return ops.Conv3x3Fn.apply(x, None, None, w, self.bias, None, None, None, cfg)
+
+
+class Linear(nn.Module):
+    """nn.Linear look-alike for the Discriminator head (models.py:205)."""
+
+    def __init__(self, in_features, out_features):
+        super().__init__()
+        ref = nn.Linear(in_features, out_features)
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = nn.Parameter(ref.weight.detach().clone())
+        self.bias = nn.Parameter(ref.bias.detach().clone())
+
+    def forward(self, x, act=ops.ACT_NONE):
+        return ops.LinearFn.apply(x, self.weight, self.bias, act)

@@ -1,0 +1,421 @@
+"""Train / rollout API of the hot path, with the reference's function signatures
+(/root/reference/main.py): train(), evaluate(), measure_prediction_mse(),
+compute_rollout_reward(), onehot(), train_mode(), test_mode().
+
+The per-iteration body follows main.py:143-297 line by line; the networks are
+scm_gan_amd.models (HIP operators), the optimizer step is the fused
+clip+Adam kernel, and under torch.distributed (one process per GPU, RCCL) the
+gradients are summed with one all-reduce per network over a flat bucket before
+the clip, so N ranks with batch B/N each reproduce one rank with batch B.
+
+Out of scope here: play() (needs a live simulator), the
+mp4/png visualisers, causal-graph rendering.
+"""
+import argparse
+import json
+import os
+import time
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import models
+from . import ops
+from .datasource import allocate_datasource
+from .logutil import TimeSeries, sparkline
+from .optim import AdamClip
+
+parser = argparse.ArgumentParser(description="Learn to model a sequential environment")
+parser.add_argument('--env', default='synthetic_minipacman', help='Datasource name (see scm_gan_amd/datasource.py)')
+parser.add_argument('--load-from', type=str, help='Directory containing .pth models to load before starting')
+parser.add_argument('--evaluate', action='store_true', help='If true, evaluate instead of training')
+parser.add_argument('--evaluations', type=int, default=1, help='Integer number of evaluations to run')
+parser.add_argument('--title', type=str, help='Name of experiment in output figures')
+parser.add_argument('--batch-size', type=int, default=32, help='Training batch size')
+parser.add_argument('--train-iters', type=int, default=10000, help='Number of iterations of training')
+parser.add_argument('--start-iter', type=int, default=1, help='Start iteration when resuming from checkpoint')
+parser.add_argument('--truncate-bptt', action='store_true', help='Train only with timestep-local information')
+parser.add_argument('--latent-overshooting', action='store_true', help='Latent Overshooting (Hafner et al.)')
+parser.add_argument('--latent-td', action='store_true', help='(dead flag in the reference, kept for CLI parity)')
+parser.add_argument('--td-lambda', type=float, default=0.9, help='Scalar lambda for overshooting')
+parser.add_argument('--td-steps', type=int, default=3, help='(dead flag in the reference)')
+parser.add_argument('--horizon-min', type=int, default=3, help='Min timestep horizon value')
+parser.add_argument('--horizon-max', type=int, default=10, help='Max timestep horizon value')
+parser.add_argument('--learning-rate', type=float, default=.0001, help='Adam lr value')
+parser.add_argument('--finetune-reward', action='store_true', help='Train ONLY the reward estimation network')
+parser.add_argument('--reward-coef', type=float, default=.001, help='Reward loss magnitude')
+parser.add_argument('--activation-l1-coef', type=float, default=.01, help='(dead flag in the reference)')
+parser.add_argument('--transition-l1-coef', type=float, default=.01, help='(dead flag in the reference)')
+parser.add_argument('--enable-action-control-loss', action='store_true', help='CF Action Control regularization')
+parser.add_argument('--enable-disentanglement-loss', action='store_true', help='CF Disentanglement regularization')
+parser.add_argument('--counterfactual-horizon', type=int, default=1, help='Forward horizon for CF generation')
+# additions of this build
+parser.add_argument('--seed', type=int, default=0, help='Seed of weights, data and the Philox latent noise')
+parser.add_argument('--eval-every', type=int, default=2000, help='Evaluate + checkpoint cadence (ITERS_PER_VIDEO)')
+parser.add_argument('--log-every', type=int, default=10)
+
+# The reference parses sys.argv at import (main.py:51); here the module-level
+# `args` holds the defaults and main() replaces it, so the API is importable.
+args = parser.parse_args([])
+
+ITERS_PER_VIDEO = 2000
+CF_REGULARIZATION_RATE = 5
+CF_REGULARIZATION_LAMBDA = .01
+
+
+def _device():
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+def _upload(a, dtype=torch.float32):
+    """numpy (any float dtype) -> fp32 device tensor (main.py:156-158)."""
+    t = torch.as_tensor(np.ascontiguousarray(a)).to(dtype)
+    return t.to(_device(), non_blocking=True)
+
+
+def onehot(a_idx, num_actions=4):
+    """main.py:447-452"""
+    eye = torch.eye(num_actions, device=_device())
+    if type(a_idx) is int:
+        return eye[a_idx].unsqueeze(0)
+    idx = torch.as_tensor(np.asarray(a_idx) if not torch.is_tensor(a_idx) else a_idx).long().to(_device())
+    return eye[idx]
+
+
+def test_mode(networks):
+    """main.py:492-497"""
+    for net in networks:
+        net.eval()
+        for child in net.children():
+            if type(child) == nn.BatchNorm2d or type(child) == nn.BatchNorm1d:
+                child.momentum = 0
+
+
+def train_mode(networks):
+    """main.py:500-505"""
+    for net in networks:
+        net.train()
+        for child in net.children():
+            if type(child) == nn.BatchNorm2d or type(child) == nn.BatchNorm1d:
+                child.momentum = 0.1
+
+
+def latent_state_loss(target, predicted):
+    """main.py:306-307"""
+    return ((target - predicted) ** 2).mean(-1).mean(-1).mean(-1)
+
+
+def decoder_pixel_loss(target, predicted_logits):
+    """main.py:310-312 fused with the torch.sigmoid of main.py:189: takes the
+    decoder LOGITS and returns the per-sample mean binary cross entropy."""
+    return ops.pixel_bce(predicted_logits, target)
+
+
+class _FlatGrads(object):
+    """Gradients of one network as views of a single flat fp32 buffer: one
+    all-reduce per network, no pack/unpack kernels."""
+
+    def __init__(self, module):
+        self.params = [p for p in module.parameters() if p.requires_grad]
+        n = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(n, device=self.params[0].device, dtype=torch.float32)
+        o = 0
+        for p in self.params:
+            p.grad = self.flat[o:o + p.numel()].view_as(p)
+            o += p.numel()
+
+    def zero(self):
+        self.flat.zero_()
+        for p in self.params:       # restore views if something replaced .grad
+            if p.grad is None or p.grad.data_ptr() < self.flat.data_ptr() or \
+                    p.grad.data_ptr() >= self.flat.data_ptr() + 4 * self.flat.numel():
+                raise RuntimeError("flat gradient view was replaced")
+
+    def all_reduce(self):
+        import torch.distributed as dist
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+
+
+def _dist():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def train(latent_dim, datasource, num_actions, num_rewards,
+          encoder, decoder, reward_predictor, discriminator, transition):
+    """main.py:106-299."""
+    batch_size = args.batch_size
+    train_iters = args.train_iters
+    td_lambda_coef = args.td_lambda
+    truncate_bptt = args.truncate_bptt
+    enable_latent_overshooting = args.latent_overshooting
+    learning_rate = args.learning_rate
+    min_prediction_horizon = args.horizon_min
+    max_prediction_horizon = args.horizon_max
+    REWARD_COEF = args.reward_coef
+    counterfactual_horizon = args.counterfactual_horizon
+    start_iter = args.start_iter
+    enable_cf_shuffle_loss = args.enable_disentanglement_loss
+    enable_control_bias_loss = args.enable_action_control_loss
+    rank, world = _dist()
+
+    # main.py:125-129 + 287-290: clip 0.1 on enc/trans/dec, none on the reward head;
+    # the discriminator's optimizer is created but never stepped in the reference.
+    opt_enc = AdamClip(encoder.parameters(), lr=learning_rate, clip_value=0.1)
+    opt_dec = AdamClip(decoder.parameters(), lr=learning_rate, clip_value=0.1)
+    opt_trans = AdamClip(transition.parameters(), lr=learning_rate, clip_value=0.1)
+    opt_disc = AdamClip(discriminator.parameters(), lr=learning_rate)      # noqa: F841
+    opt_pred = AdamClip(reward_predictor.parameters(), lr=learning_rate)
+    flats = [_FlatGrads(m) for m in (encoder, decoder, transition, reward_predictor)]
+    for o in (opt_enc, opt_dec, opt_trans, opt_pred):
+        o.grad_scale = 1.0 / world
+    ts = TimeSeries('Training Model', train_iters, tensorboard=True)
+
+    for train_iter in range(start_iter, train_iters + 1):
+        if train_iter % args.eval_every == 0:
+            if rank == 0:
+                print('Evaluating networks...')
+                evaluate(datasource, encoder, decoder, transition, discriminator, reward_predictor, latent_dim,
+                         train_iter=train_iter)
+                print('Saving networks to filesystem...')
+                torch.save(transition.state_dict(), 'model-transition.pth')
+                torch.save(encoder.state_dict(), 'model-encoder.pth')
+                torch.save(decoder.state_dict(), 'model-decoder.pth')
+                torch.save(discriminator.state_dict(), 'model-discriminator.pth')
+                torch.save(reward_predictor.state_dict(), 'model-reward_predictor.pth')
+
+        theta = train_iter / train_iters
+        pred_delta = max_prediction_horizon - min_prediction_horizon
+        prediction_horizon = min_prediction_horizon + int(pred_delta * theta)
+
+        train_mode([encoder, decoder, transition, discriminator, reward_predictor])
+        for f in flats:
+            f.zero()
+
+        states, rewards, dones, actions = datasource.get_trajectories(batch_size, prediction_horizon)
+        states = _upload(states)
+        rewards = _upload(rewards)
+        dones = _upload(np.asarray(dones).astype(int))
+        onehots = onehot(actions, num_actions)          # (B, T, A) built once per iteration
+
+        z = encoder(states[:, 0:3])
+        z_orig = z.clone()
+        active_mask = torch.ones(batch_size, device=_device())
+
+        loss = 0
+        lo_loss = 0
+        lo_z_set = {}
+        for t in range(1, prediction_horizon - 1):
+            active_mask = active_mask * (1 - dones[:, t])
+
+            expected_reward = reward_predictor(z)
+            actual_reward = rewards[:, t]
+            reward_difference = torch.mean(torch.mean((expected_reward - actual_reward) ** 2, dim=1) * active_mask)
+            ts.collect('Rd Loss t={}'.format(t), reward_difference)
+            loss += theta * REWARD_COEF * reward_difference
+
+            target_pixels = states[:, t]
+            rec_loss_batch = decoder_pixel_loss(target_pixels, decoder(z))
+            if truncate_bptt and t > 1:
+                z = z.detach()
+            rec_loss = torch.mean(rec_loss_batch * active_mask)
+            ts.collect('Reconstruction t={}'.format(t), rec_loss)
+            loss += rec_loss
+
+            new_z = transition(z, onehots[:, t])
+            z = new_z
+
+            if enable_latent_overshooting:
+                # main.py:217-230 (kept verbatim in structure, incl. its index quirks)
+                lo_z_set[t] = encoder(states[:, t - 1:t + 2])
+                for t_left in range(1, t):
+                    lo_z_set[t_left] = transition(lo_z_set[t_left], onehots[:, t - 1])
+                for t_a in range(2, t - 1):
+                    lo_loss_batch = latent_state_loss(lo_z_set[t].detach(), lo_z_set[t_a])
+                    lo_loss += td_lambda_coef * torch.mean(lo_loss_batch * active_mask)
+
+        if enable_latent_overshooting:
+            ts.collect('LO total', lo_loss)
+            loss += theta * lo_loss
+
+        if enable_cf_shuffle_loss and train_iter % CF_REGULARIZATION_RATE == 0:
+            # main.py:242-262; z_cf_b aliases z_orig and is mutated in place there
+            z_cf_a = z.clone()
+            z_cf_b = z_orig
+            unswapped_factor_map = torch.ones((batch_size, latent_dim), device=_device())
+            for i in range(batch_size):
+                idx_a = np.random.randint(latent_dim)
+                idx_b = np.random.randint(latent_dim)
+                unswapped_factor_map[i, idx_a] = 0
+                unswapped_factor_map[i, idx_b] = 0
+                z_cf_b[i, idx_a], z_cf_b[i, idx_b] = z_cf_b[i, idx_b], z_cf_b[i, idx_a]
+            for t in range(1, counterfactual_horizon):
+                z_cf_b = transition(z_cf_b, onehots[:, t])
+            cf_loss = torch.abs(z_cf_a - z_cf_b).mean(-1).mean(-1) * unswapped_factor_map
+            cf_loss = CF_REGULARIZATION_LAMBDA * torch.mean(cf_loss.mean(-1) * active_mask)
+            loss += cf_loss
+            ts.collect('CF Disentanglement Loss', cf_loss)
+
+        if enable_control_bias_loss and train_iter % CF_REGULARIZATION_RATE == 0:
+            # main.py:268-283
+            z_cf_a = z.clone()
+            z_cf_b = z_orig
+            cf_actions = actions.copy()
+            np.random.shuffle(cf_actions)
+            cf_onehots = onehot(cf_actions, num_actions)
+            for t in range(1, counterfactual_horizon):
+                z_cf_b = transition(z_cf_b, cf_onehots[:, t])
+            eps = .001
+            cf_loss = -torch.log(torch.abs(z_cf_a - z_cf_b).mean(-1).mean(-1).mean(-1) + eps)
+            cf_loss = CF_REGULARIZATION_LAMBDA * torch.mean(cf_loss * active_mask)
+            loss += cf_loss
+            ts.collect('CF Control Bias Loss', cf_loss)
+
+        loss.backward()
+
+        if world > 1:
+            for f in flats:
+                f.all_reduce()          # sum over ranks; AdamClip applies 1/world before the clip
+
+        opt_pred.step()
+        if not args.finetune_reward:
+            opt_enc.step()
+            opt_dec.step()
+            opt_trans.step()
+        if rank == 0:
+            ts.print_every(args.log_every)
+    if rank == 0:
+        print(ts)
+        print('Finished')
+    return ts
+
+
+def evaluate(datasource, encoder, decoder, transition, discriminator, reward_predictor, latent_dim, train_iter=0,
+             use_training_set=False):
+    """main.py:315-322 (numeric part; the visualisers are out of scope)."""
+    print('Evaluating networks...')
+    test_mode([encoder, decoder, transition, discriminator, reward_predictor])
+    return measure_prediction_mse(datasource, encoder, decoder, transition, reward_predictor, train_iter,
+                                  num_factors=latent_dim, use_training_set=use_training_set)
+
+
+def compute_rollout_reward(z, transition, reward_predictor, num_actions,
+                           selected_action, lookahead=2, rollout_depth=12,
+                           rollout_policy='noop', negative_positive_tradeoff=10.0):
+    """main.py:455-489: beam of num_actions**lookahead action sequences."""
+    rollout_width = num_actions ** lookahead
+    z = z.repeat(rollout_width, 1, 1, 1)
+    actions = []
+    for i in range(num_actions):
+        for j in range(num_actions):
+            if rollout_policy == 'noop':
+                actions.append([i, j] + [0] * (rollout_depth - lookahead))
+            elif rollout_policy == 'random':
+                actions.append([i, j] + [np.random.randint(num_actions) for _ in range(rollout_depth - lookahead)])
+    actions = np.array(actions)
+    assert len(actions) == rollout_width
+    cumulative_reward = reward_predictor(z).clone()
+    for t in range(rollout_depth):
+        z = z.detach()
+        z = transition(z, onehot(actions[:, t], num_actions))
+        cumulative_reward += reward_predictor(z)
+    cumulative_reward[:, 0] *= negative_positive_tradeoff
+    max_r, max_idx = cumulative_reward.sum(dim=1).max(dim=0)
+    return max_r
+
+
+def measure_prediction_mse(datasource, encoder, decoder, transition, reward_pred,
+                           train_iter=0, timesteps=100, num_factors=16, experiment_name='default',
+                           use_training_set=False, batch_size=100, write_files=True):
+    """main.py:784-855: open-loop eval rollout, per-step masked pixel / reward MSE.
+    Returns {'pixel': (means, stds), 'reward': (means, stds)} and, like the
+    reference's plot_error_graph (main.py:858-865), writes the mse_*.json files."""
+    start_time = time.time()
+    num_actions = datasource.binary_input_channels
+    states, rewards, dones, actions = datasource.get_trajectories(batch_size=batch_size, timesteps=timesteps,
+                                                                  training=use_training_set)
+    states = _upload(states)
+    rewards = _upload(rewards)
+    dones = _upload(np.asarray(dones).astype(int))
+    onehots = onehot(actions, num_actions)
+
+    z = encoder(states[:, :3])
+    z = transition(z, onehots[:, 1])
+    mse_losses, mse_stddevs, reward_losses, reward_stddevs = [], [], [], []
+    active_mask = torch.ones(batch_size, device=_device())
+    for t in range(2, timesteps):
+        active_mask = active_mask * (1 - dones[:, t])
+        if float(active_mask.sum()) == 0:
+            print('Ending simulation at max trajectory length {}'.format(t))
+            break
+        diffs = active_mask * ops.pixel_mse(decoder(z), states[:, t])
+        scale = batch_size / torch.sum(active_mask)
+        mse_losses.append(float(torch.mean(diffs) * scale))
+        mse_stddevs.append(float(torch.std(diffs) * scale))
+        r_expected = rewards[:, t].sum(-1)
+        r_predicted = reward_pred(z).sum(-1)
+        r_diffs = active_mask * (r_expected - r_predicted) ** 2
+        reward_losses.append(float(torch.mean(r_diffs) * scale))
+        reward_stddevs.append(float(torch.std(r_diffs) * scale))
+        z = transition(z, onehots[:, t])
+        z = z.detach()
+    if len(mse_losses) == 0:
+        print('Degenerate trajectory, skipping MSE calculation')
+        return None
+    print('MSE over {} timesteps: min {:.3f} max {:.3f}'.format(timesteps, min(mse_losses), max(mse_losses)))
+    print(sparkline(mse_losses, length=80))
+    print('Avg. MSE loss: {}'.format(np.mean(mse_losses)))
+    print('Finished trajectory simulation in {:.02f}s'.format(time.time() - start_time))
+    if write_files:
+        for name, (m, s) in (('pixel', (mse_losses, mse_stddevs)), ('reward', (reward_losses, reward_stddevs))):
+            with open('mse_{}_iter_{:06d}.json'.format(name, train_iter), 'w') as fp:
+                fp.write(json.dumps(m, indent=2))
+            with open('mse_stddev_{}_iter_{:06d}.json'.format(name, train_iter), 'w') as fp:
+                fp.write(json.dumps(s, indent=2))
+    return {'pixel': (mse_losses, mse_stddevs), 'reward': (reward_losses, reward_stddevs)}
+
+
+def play(*a, **k):
+    raise NotImplementedError("play() needs a live simulator (gym / gym_minipacman / sc2env): out of scope, "
+                              "SURVEY.md section 2 row 7; compute_rollout_reward() is provided")
+
+
+def main(argv=None):
+    """main.py:64-103."""
+    global args
+    args = parser.parse_args(argv)
+    torch.manual_seed(args.seed)
+    latent_dim = 16
+    datasource = allocate_datasource(args.env, seed=args.seed)
+    num_actions = datasource.binary_input_channels
+    num_rewards = datasource.scalar_output_channels
+    encoder = models.Encoder(latent_dim, datasource.conv_input_channels)
+    decoder = models.Decoder(latent_dim, datasource.conv_output_channels)
+    reward_predictor = models.RewardPredictor(latent_dim, num_rewards)
+    discriminator = models.Discriminator()
+    transition = models.Transition(latent_dim, num_actions)
+    transition.seed_noise(args.seed)
+    if args.load_from is None:
+        print('No --load-from directory specified: initializing new networks')
+    elif 'model-encoder.pth' not in os.listdir(args.load_from):
+        raise ValueError('Failed to load weights from *.pth')
+    else:
+        print('Loading models from directory {}'.format(args.load_from))
+        for net, name in ((encoder, 'encoder'), (decoder, 'decoder'), (transition, 'transition'),
+                          (discriminator, 'discriminator'), (reward_predictor, 'reward_predictor')):
+            net.load_state_dict(torch.load(os.path.join(args.load_from, 'model-{}.pth'.format(name)),
+                                           weights_only=True))
+    if args.evaluate:
+        evaluate(datasource, encoder, decoder, transition, discriminator, reward_predictor, latent_dim,
+                 use_training_set=True)
+    else:
+        train(latent_dim, datasource, num_actions, num_rewards, encoder, decoder, reward_predictor, discriminator,
+              transition)
+    print('Finished execution, terminating')
+
+
+if __name__ == '__main__':
+    main()

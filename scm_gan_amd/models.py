@@ -1,0 +1,163 @@
+"""Encoder / Transition / Decoder / RewardPredictor / Discriminator with the
+reference's constructor signatures, forward signatures and state_dict keys
+(/root/reference/models.py), computed by the HIP operators.
+
+Differences from the reference, all deliberate and documented in DESIGN.md:
+  * Transition samples its Bernoulli latent from injected uniform noise or an
+    on-device Philox stream instead of torch's global generator
+    (SURVEY.md section 8a row B);
+  * Discriminator.forward flattens before fc1 (the reference's cannot run,
+    SURVEY.md section 0.4);
+  * modules move to the GPU in their constructor only when one is visible.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .layers import Conv2d, ConvTranspose3x3, Linear
+from .spectral_normalization import SpectralNorm
+from .coordconv import CoordConv2d            # noqa: F401  (re-exported like the reference, models.py:15)
+from .spatial_recurrent import CSRN           # noqa: F401  (models.py:14)
+
+NOISE_DIM = 3
+ENCODER_INPUT_FRAMES = 3
+
+
+def _to_gpu(module):
+    if torch.cuda.is_available():
+        module.cuda()
+
+
+class Transition(nn.Module):
+    """models.py:43-119.  conv1..5 spectral-normalised, circular 3x3, U-net skips."""
+
+    def __init__(self, latent_size, num_actions):
+        super().__init__()
+        self.latent_size = latent_size
+        circ = dict(stride=1, padding=2, padding_mode='circular')
+        self.conv1 = SpectralNorm(Conv2d(latent_size + num_actions, 128, (3, 3), **circ))
+        self.conv2 = SpectralNorm(Conv2d(128, 128, (3, 3), **circ))
+        self.conv3 = SpectralNorm(Conv2d(128, 128, (3, 3), **circ))
+        self.conv4 = SpectralNorm(Conv2d(128, 128, (3, 3), **circ))
+        self.conv5 = SpectralNorm(Conv2d(128 + 128, 128, (3, 3), **circ))
+        self.conv6 = Conv2d(128 + 128, latent_size, (3, 3), **circ)
+        # Bernoulli sampling state: explicit noise tensors (parity tests) or Philox
+        self._noise_queue = []
+        self.noise_seed = 0
+        self._noise_offset = 0
+        _to_gpu(self)
+
+    def set_noise(self, tensors):
+        """Queue uniform-noise tensors (B, latent, H, W), consumed one per
+        train-mode forward call; when the queue is empty the on-device Philox
+        stream (noise_seed, running offset) is used."""
+        self._noise_queue = list(tensors)
+
+    def seed_noise(self, seed, offset=0):
+        self.noise_seed, self._noise_offset = int(seed), int(offset)
+
+    def forward(self, s, a, return_all=False):
+        batch_size, z, height, width = s.shape
+        batch_size_actions, num_actions = a.shape
+        assert batch_size == batch_size_actions
+        L = ops.ACT_LRELU
+        # the action planes (models.py:68-73) enter conv1 as a per-sample bias
+        skip1 = self.conv1(s, None, a, act=L)
+        skip2 = self.conv2(skip1, act=L)
+        out3 = self.conv3(skip2, act=L)
+        out4 = self.conv4(out3, act=L)
+        out5 = self.conv5(out4, skip2, act=L)                 # cat([x, skip2]) never materialised
+        p = self.conv6(out5, skip1, act=ops.ACT_SIGMOID)      # cat([x, skip1])
+        if self.training:
+            if self._noise_queue:
+                x = ops.BernoulliSTFn.apply(p, self._noise_queue.pop(0), 1, 0, 0)
+            else:
+                x = ops.BernoulliSTFn.apply(p, None, 2, self.noise_seed, self._noise_offset)
+                self._noise_offset += (p.numel() + 3) // 4
+        else:
+            x = ops.threshold(p)
+        if return_all:
+            return (skip1, skip2, out3, out4, out5, x)
+        return x
+
+
+class Encoder(nn.Module):
+    """models.py:123-157."""
+
+    def __init__(self, latent_size, color_channels):
+        super().__init__()
+        self.latent_size = latent_size
+        self.color_channels = color_channels
+        self.conv1 = SpectralNorm(Conv2d(color_channels * ENCODER_INPUT_FRAMES, 128, (3, 3), stride=1, padding=1))
+        self.bn_conv1 = nn.BatchNorm2d(128)     # registered but never applied (models.py:130,145-155)
+        self.conv2 = SpectralNorm(Conv2d(128, 128, (3, 3), stride=1, padding=1))
+        self.conv3 = SpectralNorm(Conv2d(128, 128, (3, 3), stride=1, padding=1))
+        self.conv4 = Conv2d(128, latent_size, (3, 3), stride=1, padding=1)
+        _to_gpu(self)
+
+    def forward(self, x):
+        batch_size, frames, channels, height, width = x.shape
+        x = x.reshape(batch_size, frames * channels, height, width)
+        x = self.conv1(x, act=ops.ACT_LRELU)
+        x = self.conv2(x, act=ops.ACT_LRELU)
+        x = self.conv3(x, act=ops.ACT_LRELU)
+        return self.conv4(x, act=ops.ACT_SIGMOID)
+
+
+class Discriminator(nn.Module):
+    """models.py:195-223 (+ the flatten in front of fc1)."""
+
+    def __init__(self):
+        super().__init__()
+        self.conv1 = SpectralNorm(Conv2d(NOISE_DIM, 32, (3, 3), stride=2, padding=0))
+        self.conv2 = SpectralNorm(Conv2d(32, 32, (3, 3), stride=2, padding=0))
+        self.conv3 = Conv2d(32, 32, (3, 3), stride=2, padding=0)
+        self.fc1 = Linear(32 * 7 * 7, 1)
+        _to_gpu(self)
+
+    def forward(self, x):
+        x = self.conv1(x, act=ops.ACT_LRELU)
+        x = self.conv2(x, act=ops.ACT_LRELU)
+        x = self.conv3(x, act=ops.ACT_LRELU)
+        x = x.reshape(x.shape[0], -1)
+        return self.fc1(x, act=ops.ACT_LRELU)
+
+
+class RewardPredictor(nn.Module):
+    """models.py:226-250."""
+
+    def __init__(self, latent_dim, num_rewards):
+        super().__init__()
+        self.num_rewards = num_rewards
+        self.conv1 = Conv2d(latent_dim, 32, (3, 3), stride=1, padding=0)
+        self.conv2 = Conv2d(32, num_rewards * 3, (3, 3), stride=2, padding=0)
+        _to_gpu(self)
+
+    def forward(self, x, visualize=False):
+        x = self.conv1(x, act=ops.ACT_LRELU)
+        x = self.conv2(x)
+        r, rmap = ops.RewardTailFn.apply(x, self.num_rewards)
+        if visualize:
+            return r, rmap
+        return r
+
+
+class Decoder(nn.Module):
+    """models.py:253-291."""
+
+    def __init__(self, latent_size, color_channels):
+        super().__init__()
+        self.latent_size = latent_size
+        self.color_channels = color_channels
+        self.conv1 = ConvTranspose3x3(latent_size, latent_size * 4)
+        self.conv2 = ConvTranspose3x3(latent_size * 4, latent_size * self.color_channels)
+        _to_gpu(self)
+
+    def forward(self, z_map, visualize=False):
+        batch_size, latent_size, height, width = z_map.shape
+        x = self.conv1(z_map, act=ops.ACT_LRELU)
+        x = self.conv2(x)
+        out = ops.FactorSumFn.apply(x, latent_size, self.color_channels)
+        if visualize:
+            return out, x.view(batch_size, latent_size, self.color_channels, height, width)[0]
+        return out

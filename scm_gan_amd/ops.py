@@ -1,0 +1,365 @@
+"""Operators of the hot path as torch.autograd.Functions over the C ABI
+(include/scm_hip.h).  PyTorch owns memory, streams and the graph topology;
+every FLOP and byte of these operators runs in libscmgan_hip.so.  There is no
+fallback: tensors must be fp32 CUDA tensors and the library must be built.
+"""
+import ctypes
+
+import torch
+from torch.autograd import Function
+
+from . import _lib as L
+
+PAD_ZERO, PAD_CIRCULAR = L.PAD_ZERO, L.PAD_CIRCULAR
+ACT_NONE, ACT_LRELU, ACT_SIGMOID = L.ACT_NONE, L.ACT_LRELU, L.ACT_SIGMOID
+
+
+# Bumped by optimizers that update parameters through raw device pointers (which
+# torch's tensor version counter cannot see); part of every weight-pack cache key.
+_weights_epoch = [0]
+
+
+def weights_epoch():
+    return _weights_epoch[0]
+
+
+def bump_weights_epoch():
+    _weights_epoch[0] += 1
+
+
+def _chk(t, name):
+    if t is None:
+        return None
+    if not t.is_cuda or t.dtype != torch.float32:
+        raise RuntimeError("scm_gan_amd.%s: expected an fp32 tensor on the GPU (got %s on %s); "
+                           "there is no CPU fallback" % (name, t.dtype, t.device))
+    return t.contiguous()
+
+
+def _new(like, *shape):
+    return torch.empty(shape, device=like.device, dtype=torch.float32)
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# ------------------------------------------------------------------ packs
+def pack_conv3x3(weight, cin, cout, transposed=False, cin_total=0, ci0=0):
+    """Weight packs (forward, dgrad) for scm_conv3x3 from a torch-layout weight."""
+    lib = L.lib()
+    w = _chk(weight.detach(), "pack_conv3x3")
+    fp = _new(w, lib.scm_conv3x3_pack_floats(cin, cout))
+    dp = _new(w, lib.scm_conv3x3_pack_floats(cout, cin))
+    L.check(lib.scm_pack_conv3x3_weights(_p(w), cin, cout, int(transposed), cin_total, ci0, _p(fp), _p(dp), _stream()),
+            "scm_pack_conv3x3_weights")
+    return fp, dp
+
+
+def _conv3x3_raw(x1, x2, gate1, gate2, gate_act, wpack, cout, scale, bias, sbias, co1, pad, act):
+    lib = L.lib()
+    B, c1, H, W = x1.shape
+    c2 = 0 if x2 is None else x2.shape[1]
+    y1 = _new(x1, B, co1, H, W)
+    y2 = _new(x1, B, cout - co1, H, W) if co1 < cout else None
+    d = L.ConvDesc(_p(x1), _p(x2), c1, c2, _p(gate1), _p(gate2), gate_act, _p(wpack), cout, _p(scale), _p(bias),
+                   _p(sbias), _p(y1), _p(y2), co1, B, H, W, pad, act)
+    L.check(lib.scm_conv3x3(ctypes.byref(d), _stream()), "scm_conv3x3")
+    return y1, y2
+
+
+def sn_power_iter(weight_bar, u, v):
+    """One SpectralNorm._update_u_v call (spectral_normalization.py:23-35):
+    updates u, v in place, returns (sigma, inv_sigma) as 1-element tensors."""
+    lib = L.lib()
+    w = _chk(weight_bar.detach(), "sn_power_iter")
+    rows = w.shape[0]
+    cols = w.numel() // rows
+    out = _new(w, 2)
+    sigma, inv_sigma = out[0:1], out[1:2]
+    layer = L.SnLayer(_p(w), _p(u.data), _p(v.data), _p(sigma), _p(inv_sigma), rows, cols)
+    L.check(lib.scm_sn_power_iter(1, ctypes.byref(layer), 1, _stream()), "scm_sn_power_iter")
+    return sigma, inv_sigma
+
+
+def _sn_fold(g, weight_bar, u, v, inv_sigma):
+    lib = L.lib()
+    rows = weight_bar.shape[0]
+    cols = weight_bar.numel() // rows
+    out = torch.empty_like(g)
+    L.check(lib.scm_sn_fold_grad(_p(g), _p(weight_bar), _p(u), _p(v), _p(inv_sigma), rows, cols, 0, _p(out), _stream()),
+            "scm_sn_fold_grad")
+    return out
+
+
+# -------------------------------------------------------------- conv 3x3
+class Conv3x3Fn(Function):
+    """y = act(conv3x3(cat(x1, x2), W_eff) + bias [+ action-plane bias]),
+    W_eff = weight * inv_sigma (SpectralNorm) or weight.
+
+    cfg: pad, act, transposed (ConvTranspose2d weight layout), packs (fwd, dgrad),
+         cin_conv (input channels convolved; the remaining weight channels are
+         the action planes folded into a per-sample bias).
+    """
+
+    @staticmethod
+    def forward(ctx, x1, x2, act_vec, weight, bias, inv_sigma, u, v, cfg):
+        lib = L.lib()
+        x1 = _chk(x1, "conv3x3")
+        x2 = _chk(x2, "conv3x3")
+        act_vec = _chk(act_vec, "conv3x3")
+        w = _chk(weight.detach(), "conv3x3")
+        B, c1, H, W = x1.shape
+        c2 = 0 if x2 is None else x2.shape[1]
+        cout = w.shape[1] if cfg["transposed"] else w.shape[0]
+        cin_total = w.shape[0] if cfg["transposed"] else w.shape[1]
+        fpack, dpack = cfg["packs"]
+        sbias = None
+        if act_vec is not None:
+            A = act_vec.shape[1]
+            assert c1 + c2 + A == cin_total
+            sbias = _new(x1, B, cout)
+            L.check(lib.scm_action_bias(_p(act_vec), _p(w), _p(inv_sigma), B, A, cout, cin_total, c1 + c2, _p(sbias),
+                                        _stream()), "scm_action_bias")
+        y, _ = _conv3x3_raw(x1, x2, None, None, 0, fpack, cout, inv_sigma, bias, sbias, cout, cfg["pad"], cfg["act"])
+        ctx.cfg = cfg
+        ctx.shape = (B, c1, c2, H, W, cout, cin_total)
+        ctx.has = (x2 is not None, act_vec is not None, bias is not None, inv_sigma is not None)
+        ctx.save_for_backward(x1, x2, act_vec, w, inv_sigma, u, v, y, dpack)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = L.lib()
+        x1, x2, act_vec, w, inv_sigma, u, v, y, dpack = ctx.saved_tensors
+        cfg = ctx.cfg
+        B, c1, c2, H, W, cout, cin_total = ctx.shape
+        gy = _chk(gy, "conv3x3.backward")
+        act = cfg["act"]
+        need_x1, need_x2, need_a, need_w, need_b = ctx.needs_input_grad[:5]
+        dx1 = dx2 = d_act = dw = db = None
+        if need_x1 or need_x2:
+            dx1, dx2 = _conv3x3_raw(gy, None, y if act else None, None, act, dpack, c1 + c2, inv_sigma, None, None, c1,
+                                    cfg["pad"], ACT_NONE)
+        if need_w or need_b or need_a:
+            pf, cf = ctypes.c_size_t(), ctypes.c_size_t()
+            L.check(lib.scm_conv3x3_wgrad_workspace(B, H, W, c1 + c2, cout, ctypes.byref(pf), ctypes.byref(cf)),
+                    "scm_conv3x3_wgrad_workspace")
+            part = _new(gy, pf.value)
+            cws = _new(gy, cf.value)
+            has_act = act_vec is not None
+            # dw_eff: gradient w.r.t. the effective weight, in the parameter's layout
+            dw_eff = torch.empty_like(w)
+            db = _new(gy, cout)
+            csum = _new(gy, B, cout) if has_act else None
+            d = L.WgradDesc(_p(x1), _p(x2), c1, c2, _p(gy), _p(y) if act else None, act, cout, _p(dw_eff), _p(db),
+                            _p(csum), _p(part), _p(cws), B, H, W, cfg["pad"], int(cfg["transposed"]), 0,
+                            cin_total, 0)
+            L.check(lib.scm_conv3x3_wgrad(ctypes.byref(d), _stream()), "scm_conv3x3_wgrad")
+            if has_act:
+                A = act_vec.shape[1]
+                d_act = _new(gy, B, A)
+                L.check(lib.scm_action_bias_bwd(_p(act_vec), _p(w), _p(inv_sigma), _p(csum), B, A, cout, cin_total,
+                                                c1 + c2, _p(d_act), _p(dw_eff), _stream()), "scm_action_bias_bwd")
+            if inv_sigma is not None:
+                dw = _sn_fold(dw_eff, w, u, v, inv_sigma)
+            else:
+                dw = dw_eff
+        return (dx1 if need_x1 else None, dx2 if need_x2 else None, d_act if need_a else None,
+                dw if need_w else None, db if need_b else None, None, None, None, None)
+
+
+# ------------------------------------------------------------ small conv
+class Conv2dFn(Function):
+    """Generic small Conv2d (K, stride, pad) + activation; optional SpectralNorm."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, inv_sigma, u, v, K, stride, pad, act):
+        lib = L.lib()
+        x = _chk(x, "conv2d")
+        w = _chk(weight.detach(), "conv2d")
+        B, cin, H, W = x.shape
+        cout = w.shape[0]
+        OH, OW = (H + 2 * pad - K) // stride + 1, (W + 2 * pad - K) // stride + 1
+        y = _new(x, B, cout, OH, OW)
+        d = L.Conv2dDesc(_p(x), _p(w), _p(bias), _p(inv_sigma), _p(y), None, 0, B, cin, H, W, cout, K, stride, pad, act)
+        L.check(lib.scm_conv2d_fwd(ctypes.byref(d), _stream()), "scm_conv2d_fwd")
+        ctx.geom = (B, cin, H, W, cout, K, stride, pad, act)
+        ctx.save_for_backward(x, w, inv_sigma, u, v, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = L.lib()
+        x, w, inv_sigma, u, v, y = ctx.saved_tensors
+        B, cin, H, W, cout, K, stride, pad, act = ctx.geom
+        gy = _chk(gy, "conv2d.backward")
+        need_x, need_w, need_b = ctx.needs_input_grad[:3]
+        dx = torch.empty_like(x) if need_x else None
+        dw_eff = torch.empty_like(w) if (need_w or need_b) else None
+        db = _new(gy, cout) if (need_w or need_b) else None
+        d = L.Conv2dDesc(_p(x), _p(w), None, _p(inv_sigma), None, _p(y) if act else None, act, B, cin, H, W, cout, K,
+                         stride, pad, act)
+        L.check(lib.scm_conv2d_bwd(ctypes.byref(d), _p(gy), _p(dx), _p(dw_eff), _p(db), 0, _stream()), "scm_conv2d_bwd")
+        dw = dw_eff
+        if dw_eff is not None and inv_sigma is not None:
+            dw = _sn_fold(dw_eff, w, u, v, inv_sigma)
+        return dx, dw if need_w else None, db if need_b else None, None, None, None, None, None, None, None
+
+
+# ----------------------------------------------------------- elementwise
+class BernoulliSTFn(Function):
+    """DifferentiableBernoulliSampler (models.py:29-40): forward samples
+    (noise < p), backward passes the gradient through unchanged."""
+
+    @staticmethod
+    def forward(ctx, p, noise, mode, seed, offset):
+        p = _chk(p, "bernoulli")
+        noise = _chk(noise, "bernoulli")
+        out = torch.empty_like(p)
+        L.check(L.lib().scm_bernoulli(_p(p), _p(noise), _p(out), p.numel(), mode, seed, offset, _stream()),
+                "scm_bernoulli")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None, None, None, None
+
+
+def threshold(p):
+    """Eval-mode latent: (p > 0.5), models.py:110-113 (no gradient)."""
+    p = _chk(p.detach(), "threshold")
+    out = torch.empty_like(p)
+    L.check(L.lib().scm_bernoulli(_p(p), None, _p(out), p.numel(), 0, 0, 0, _stream()), "scm_bernoulli")
+    return out
+
+
+class FactorSumFn(Function):
+    """x.view(B, L, C, H, W).sum(1), models.py:280-287."""
+
+    @staticmethod
+    def forward(ctx, x, L_, C):
+        x = _chk(x, "factor_sum")
+        B, _, H, W = x.shape
+        y = _new(x, B, C, H, W)
+        L.check(L.lib().scm_factor_sum(_p(x), _p(y), B, L_, C, H * W, _stream()), "scm_factor_sum")
+        ctx.geom = (B, L_, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        B, L_, C, H, W = ctx.geom
+        gy = _chk(gy, "factor_sum.backward")
+        dx = _new(gy, B, L_ * C, H, W)
+        L.check(L.lib().scm_factor_bcast(_p(gy), _p(dx), B, L_, C, H * W, _stream()), "scm_factor_bcast")
+        return dx, None, None
+
+
+class PixelLossFn(Function):
+    """per_sample[b] = mean_{chw} loss(sigmoid(logit), target); kind 0 = BCE
+    (main.py:189-190,310-312), kind 1 = squared error (main.py:814-816)."""
+
+    @staticmethod
+    def forward(ctx, logit, target, kind):
+        logit = _chk(logit, "pixel_loss")
+        target = _chk(target, "pixel_loss")
+        B = logit.shape[0]
+        n = logit.numel() // B
+        out = _new(logit, B)
+        L.check(L.lib().scm_pixel_loss(_p(logit), _p(target), B, n, kind, _p(out), None, _stream()), "scm_pixel_loss")
+        ctx.kind = kind
+        ctx.save_for_backward(logit, target)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        logit, target = ctx.saved_tensors
+        g = _chk(g, "pixel_loss.backward")
+        B = logit.shape[0]
+        n = logit.numel() // B
+        d = torch.empty_like(logit)
+        L.check(L.lib().scm_pixel_loss_bwd(_p(logit), _p(target), _p(g), B, n, ctx.kind, _p(d), _stream()),
+                "scm_pixel_loss_bwd")
+        return d, None, None
+
+
+class RewardTailFn(Function):
+    """softmax over 3 classes -> p0 - p2 -> (sum over h,w ; map), models.py:241-250."""
+
+    @staticmethod
+    def forward(ctx, x, R):
+        x = _chk(x, "reward_tail")
+        B, _, h, w = x.shape
+        r = _new(x, B, R)
+        m = _new(x, B, R, h, w)
+        L.check(L.lib().scm_reward_tail(_p(x), B, R, h * w, _p(r), _p(m), _stream()), "scm_reward_tail")
+        ctx.geom = (B, R, h, w)
+        ctx.save_for_backward(x)
+        return r, m
+
+    @staticmethod
+    def backward(ctx, g_r, g_map):
+        (x,) = ctx.saved_tensors
+        B, R, h, w = ctx.geom
+        g_r = _chk(g_r, "reward_tail.backward")
+        g_map = _chk(g_map, "reward_tail.backward")
+        dx = torch.empty_like(x)
+        L.check(L.lib().scm_reward_tail_bwd(_p(x), _p(g_r), _p(g_map), B, R, h * w, _p(dx), _stream()),
+                "scm_reward_tail_bwd")
+        return dx, None
+
+
+class LinearFn(Function):
+    """act(x w^T + b), models.py:205,221-222."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act):
+        x = _chk(x, "linear")
+        w = _chk(weight.detach(), "linear")
+        B, nin = x.shape
+        nout = w.shape[0]
+        y = _new(x, B, nout)
+        L.check(L.lib().scm_linear(_p(x), _p(w), _p(bias), B, nin, nout, act, _p(y), _stream()), "scm_linear")
+        ctx.act = act
+        ctx.save_for_backward(x, w, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, y = ctx.saved_tensors
+        gy = _chk(gy, "linear.backward")
+        B, nin = x.shape
+        nout = w.shape[0]
+        dx, dw, db = torch.empty_like(x), torch.empty_like(w), _new(gy, nout)
+        L.check(L.lib().scm_linear_bwd(_p(x), _p(w), _p(y), _p(gy), B, nin, nout, ctx.act, _p(dx), _p(dw), _p(db),
+                                       _stream()), "scm_linear_bwd")
+        return dx, dw, db, None
+
+
+class CoordCatFn(Function):
+    """cat([x, coord_x, coord_y], 1), coordconv.py:12-14."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _chk(x, "coord_cat")
+        B, C, H, W = x.shape
+        out = _new(x, B, C + 2, H, W)
+        L.check(L.lib().scm_coord_cat(_p(x), _p(out), B, C, H, W, _stream()), "scm_coord_cat")
+        ctx.C = C
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[:, :ctx.C].contiguous()
+
+
+def pixel_mse(logit, target):
+    return PixelLossFn.apply(logit, target, 1)
+
+
+def pixel_bce(logit, target):
+    return PixelLossFn.apply(logit, target, 0)

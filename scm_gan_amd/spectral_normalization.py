@@ -1,0 +1,71 @@
+"""SpectralNorm wrapper with the reference's interface and state layout.
+
+Mirrors /root/reference/spectral_normalization.py:14-68: wraps a module, removes
+its `weight` parameter and registers `weight_u`, `weight_v` (requires_grad=False)
+and `weight_bar` ON THE WRAPPED MODULE, runs ONE power iteration on EVERY forward
+call (train, eval and no_grad alike -- SURVEY.md section 0.6) and normalises the
+weight by sigma = u . (W_bar v).  The power iteration, the 1/sigma scaling (in
+the conv epilogue) and the gradient through sigma are HIP kernels
+(csrc/sn.hip); W_bar / sigma is never materialised.
+"""
+import torch
+from torch import nn
+from torch.nn import Parameter
+
+from . import ops
+
+
+def l2normalize(v, eps=1e-12):
+    return v / (v.norm() + eps)
+
+
+class SpectralNorm(nn.Module):
+    def __init__(self, module, name='weight', power_iterations=1):
+        super(SpectralNorm, self).__init__()
+        self.module = module
+        self.name = name
+        self.power_iterations = power_iterations
+        if not self._made_params():
+            self._make_params()
+
+    def _made_params(self):
+        try:
+            getattr(self.module, self.name + "_u")
+            getattr(self.module, self.name + "_v")
+            getattr(self.module, self.name + "_bar")
+            return True
+        except AttributeError:
+            return False
+
+    def _make_params(self):
+        # spectral_normalization.py:47-63: u, v ~ N(0,1) normalised; weight -> weight_bar
+        w = getattr(self.module, self.name)
+        height = w.data.shape[0]
+        width = w.view(height, -1).data.shape[1]
+        u = Parameter(w.data.new(height).normal_(0, 1), requires_grad=False)
+        v = Parameter(w.data.new(width).normal_(0, 1), requires_grad=False)
+        u.data = l2normalize(u.data)
+        v.data = l2normalize(v.data)
+        w_bar = Parameter(w.data)
+        del self.module._parameters[self.name]
+        self.module.register_parameter(self.name + "_u", u)
+        self.module.register_parameter(self.name + "_v", v)
+        self.module.register_parameter(self.name + "_bar", w_bar)
+
+    def _update_u_v(self):
+        """Power iteration(s) on the device; returns (sigma, inv_sigma)."""
+        u = getattr(self.module, self.name + "_u")
+        v = getattr(self.module, self.name + "_v")
+        w = getattr(self.module, self.name + "_bar")
+        sigma = inv_sigma = None
+        for _ in range(self.power_iterations):
+            sigma, inv_sigma = ops.sn_power_iter(w, u, v)
+        return w, u, v, sigma, inv_sigma
+
+    def forward(self, *args, **kwargs):
+        w, u, v, sigma, inv_sigma = self._update_u_v()
+        if self.name != 'weight' or not hasattr(self.module, "forward") or \
+                "_sn" not in self.module.forward.__code__.co_varnames:
+            raise TypeError("scm_gan_amd.SpectralNorm wraps scm_gan_amd.layers modules (Conv2d); got %r"
+                            % type(self.module).__name__)
+        return self.module.forward(*args, _sn=(w, u, v, inv_sigma), **kwargs)
