@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""Headline benchmark: predicted frames/s of the action-conditional
+frame-prediction TRAINING iteration (encoder -> (reward head, decoder + BCE,
+transition) x (horizon-2) -> backward -> clip -> Adam; reference main.py:143-297)
+on synthetic minipacman-shaped rollouts (64x64x3, horizon 10, A=5, R=2).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL all-reduce)
+
+Per-GPU batch is fixed at 64 (BASELINE.json configs[1]), so scaling is weak and
+`value` counts the frames of all ranks.  Inputs are resident in HBM before the
+timed region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+H = W = 64
+C, A, R, L = 3, 5, 2, 16
+
+
+def algorithmic_gflop_per_frame(horizon):
+    """2*MAC, train = 3x forward, per predicted frame."""
+    enc = 2.652
+    step = 6.540 + 0.302 + 0.0385
+    return 3.0 * (enc + (horizon - 2) * step) / (horizon - 2)
+
+
+def build_nets(seed):
+    from scm_gan_amd import models
+    torch.manual_seed(seed)
+    enc = models.Encoder(L, C)
+    dec = models.Decoder(L, C)
+    rp = models.RewardPredictor(L, R)
+    disc = models.Discriminator()
+    tr = models.Transition(L, A)
+    return enc, dec, rp, disc, tr
+
+
+def make_batch(ds, batch, horizon, dev):
+    from scm_gan_amd import main as M
+    states, rewards, dones, actions = ds.get_trajectories(batch, horizon)
+    return (torch.as_tensor(states, dtype=torch.float32).to(dev), torch.as_tensor(rewards, dtype=torch.float32).to(dev),
+            torch.as_tensor(dones.astype(np.float32)).to(dev), M.onehot(actions, A))
+
+
+def host_cores():
+    """CPU share of this process: affinity mask, capped by the cgroup quota (the
+    GPU box exposes every host core but grants 16 per GPU)."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("SCM_BENCH_CPU_THREADS", "16"))))
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """Reference CPU path (the oracle: same arithmetic as the reference's torch-CPU
+    modules, pinned to them by tests/test_oracle_golden.py) on BASELINE configs[0]:
+    64x64, batch 8, horizon 5, timed on this box's host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import weights as WS
+    from oracle import scm_oracle as O
+    from scm_gan_amd.datasource import SyntheticDatasource
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    B, h = 8, 5
+    enc, tr, dec, rp = (O.clone_state(s) for s in (WS.encoder_state(0), WS.transition_state(1), WS.decoder_state(2),
+                                                   WS.reward_state(3)))
+    trainer = O.Trainer(enc, tr, dec, rp, A)
+    ds = SyntheticDatasource(seed=0, height=H, width=W, channels=C, num_actions=A, num_rewards=R)
+    rng = np.random.default_rng(0)
+
+    def one():
+        st, rw, dn, ac = ds.get_trajectories(B, h)
+        noises = [torch.from_numpy(rng.random((B, L, H, W), dtype=np.float32)) for _ in range(h - 2)]
+        trainer.step(st, rw, dn, ac, 0.5, noises)
+    one()
+    t0 = time.time()
+    n = 0
+    while n < 1 or (time.time() - t0 < seconds_budget and n < 50):
+        one()
+        n += 1
+        sys.stderr.write("[bench] cpu_baseline iteration %d, %.1f s\n" % (n, time.time() - t0))
+        sys.stderr.flush()
+    dt = time.time() - t0
+    return {"value": B * (h - 2) * n / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "%d training iterations of configs[0] (64x64x3, batch 8, horizon 5), %.1f s, torch %s CPU ops "
+                      "via oracle/scm_oracle.py" % (n, dt, torch.__version__)}
+
+
+def rollout_l1(dev):
+    """Mean per-pixel |sigmoid(decoder(z_t))_hip - _oracle| over a free-running
+    eval rollout (main.py:798-835 pattern), B=2, 64x64, 10 steps, same weights."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import weights as WS
+    from oracle import scm_oracle as O
+    from scm_gan_amd import models, main as M
+    from scm_gan_amd.datasource import SyntheticDatasource
+    ds = SyntheticDatasource(seed=11, height=H, width=W, channels=C, num_actions=A, num_rewards=R)
+    states, rewards, dones, actions = ds.get_trajectories(2, 12, training=False)
+    enc, tr, dec = models.Encoder(L, C), models.Transition(L, A), models.Decoder(L, C)
+    enc.load_state_dict(WS.to_torch(WS.encoder_state(0)))
+    tr.load_state_dict(WS.to_torch(WS.transition_state(1)))
+    dec.load_state_dict(WS.to_torch(WS.decoder_state(2)))
+    M.test_mode([enc, tr, dec])
+    oenc, otr, odec = (O.clone_state(s) for s in (WS.encoder_state(0), WS.transition_state(1), WS.decoder_state(2)))
+    orp = O.clone_state(WS.reward_state(3))
+    ref = O.measure_prediction_mse(oenc, otr, odec, orp, states, rewards, dones, actions, A, return_frames=True)
+    with torch.no_grad():
+        st = torch.as_tensor(states, dtype=torch.float32).to(dev)
+        oh = M.onehot(actions, A)
+        z = enc(st[:, :3])
+        z = tr(z, oh[:, 1])
+        l1, flips = [], 0
+        for i, t in enumerate(range(2, 12)):
+            pred = torch.sigmoid(dec(z)).cpu()
+            l1.append(float((pred - ref["frames"][i]).abs().mean()))
+            flips += int((z.cpu() != ref["z"][i]).sum())
+            z = tr(z, oh[:, t])
+    return float(np.mean(l1)), flips
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (BASELINE configs[1])")
+    ap.add_argument("--horizon", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % a.gpus)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    from scm_gan_amd import main as M, ops
+    from scm_gan_amd.datasource import SyntheticDatasource
+    opts = M.parser.parse_args(["--train-iters", str(a.steps + a.warmup), "--horizon-min", str(a.horizon),
+                                "--horizon-max", str(a.horizon), "--batch-size", str(a.batch)])
+    enc, dec, rp, disc, tr = build_nets(0)          # identical replicas on every rank
+    tr.seed_noise(1234 + rank)                      # rank-offset Philox stream
+    trainer = M.Trainer(L, A, R, enc, dec, rp, disc, tr, opts)
+    ds = SyntheticDatasource(seed=rank, height=H, width=W, channels=C, num_actions=A, num_rewards=R)
+    batches = [make_batch(ds, a.batch, a.horizon, dev) for _ in range(2)]    # resident in HBM
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        trainer.step(*batches[i % 2], theta=0.5, train_iter=i + 1)
+    timer = None
+    if not a.no_kernel_timer and rank == 0:
+        timer = ops.KernelTimer()
+        ops.kernel_timer = timer
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        trainer.step(*batches[i % 2], theta=0.5, train_iter=a.warmup + i + 1)
+    barrier()
+    dt = time.perf_counter() - t0
+    ops.kernel_timer = None
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        frames = a.batch * world * (a.horizon - 2) * a.steps
+        value = frames / dt
+        out = {
+            "metric": "predicted frames/sec/node (minipacman 64x64, horizon=10) + rollout L1 vs ref",
+            "value": value, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: minipacman-shaped 64x64x3, per-GPU batch %d, horizon %d, A=5, R=2, "
+                                   "training iteration fwd+bwd+clip+Adam, reference loss (BCE + reward MSE), no "
+                                   "discriminator" % (a.batch, a.horizon),
+                       "global_batch": a.batch * world, "horizon": a.horizon, "parallelism": "dp%d" % world},
+            "algorithmic_tflops": value * algorithmic_gflop_per_frame(a.horizon) / 1e3,
+        }
+        if timer is not None:
+            summ = timer.summary()
+            dom = max(summ.items(), key=lambda kv: kv[1]["ms"])
+            name, s = dom
+            achieved = s["flops"] / (s["ms"] * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
+                               "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                               "launches": s["launches"], "avg_launch_us": s["ms"] * 1e3 / s["launches"],
+                               "share_of_step": s["ms"] / (dt * 1e3)}
+            out["kernels"] = {k: {"launches": v["launches"], "ms_total": round(v["ms"], 3),
+                                  "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12} for k, v in summ.items()}
+        if world == 1:
+            l1, flips = rollout_l1(dev)
+            out["rollout_l1_vs_ref"] = l1
+            out["rollout_latent_flips"] = flips
+            if not a.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -144,37 +144,144 @@ def _dist():
     return 0, 1
 
 
+class Trainer(object):
+    """One training iteration of main.py:143-297 on device-resident batches.
+
+    train() below feeds it from a datasource exactly as the reference does;
+    bench.py feeds it batches that already live in HBM."""
+
+    def __init__(self, latent_dim, num_actions, num_rewards, encoder, decoder, reward_predictor, discriminator,
+                 transition, opts=None):
+        self.a = opts if opts is not None else args
+        self.latent_dim, self.num_actions, self.num_rewards = latent_dim, num_actions, num_rewards
+        self.encoder, self.decoder, self.reward_predictor = encoder, decoder, reward_predictor
+        self.discriminator, self.transition = discriminator, transition
+        self.rank, self.world = _dist()
+        lr = self.a.learning_rate
+        # main.py:125-129 + 287-290: clip 0.1 on enc/trans/dec, none on the reward head;
+        # the discriminator's optimizer is created but never stepped in the reference.
+        self.opt_enc = AdamClip(encoder.parameters(), lr=lr, clip_value=0.1)
+        self.opt_dec = AdamClip(decoder.parameters(), lr=lr, clip_value=0.1)
+        self.opt_trans = AdamClip(transition.parameters(), lr=lr, clip_value=0.1)
+        self.opt_disc = AdamClip(discriminator.parameters(), lr=lr)
+        self.opt_pred = AdamClip(reward_predictor.parameters(), lr=lr)
+        self.flats = [_FlatGrads(m) for m in (encoder, decoder, transition, reward_predictor)]
+        for o in (self.opt_enc, self.opt_dec, self.opt_trans, self.opt_pred):
+            o.grad_scale = 1.0 / self.world
+        self.ts = TimeSeries('Training Model', self.a.train_iters, tensorboard=True)
+
+    def step(self, states, rewards, dones, onehots, theta, train_iter=1, actions=None):
+        """states (B,T,C,H,W), rewards (B,T,R), dones (B,T) as 0/1 floats, onehots
+        (B,T,A): fp32 device tensors.  Returns the (device) loss."""
+        a = self.a
+        ts = self.ts
+        encoder, decoder, reward_predictor, transition = self.encoder, self.decoder, self.reward_predictor, \
+            self.transition
+        batch_size, prediction_horizon = states.shape[0], states.shape[1]
+        latent_dim = self.latent_dim
+        cf_now = train_iter % CF_REGULARIZATION_RATE == 0
+        enable_cf_shuffle_loss = a.enable_disentanglement_loss and cf_now
+        enable_control_bias_loss = a.enable_action_control_loss and cf_now
+
+        train_mode([encoder, decoder, transition, self.discriminator, reward_predictor])
+        for f in self.flats:
+            f.zero()
+
+        z = encoder(states[:, 0:3])                                            # main.py:162
+        z_orig = z.clone() if (enable_cf_shuffle_loss or enable_control_bias_loss) else None
+        active_mask = torch.ones(batch_size, device=states.device)
+
+        loss = 0
+        lo_loss = 0
+        lo_z_set = {}
+        for t in range(1, prediction_horizon - 1):                             # main.py:177
+            active_mask = active_mask * (1 - dones[:, t])
+
+            expected_reward = reward_predictor(z)
+            actual_reward = rewards[:, t]
+            reward_difference = torch.mean(torch.mean((expected_reward - actual_reward) ** 2, dim=1) * active_mask)
+            ts.collect('Rd Loss t={}'.format(t), reward_difference)
+            loss += theta * a.reward_coef * reward_difference                  # main.py:185
+
+            rec_loss_batch = decoder_pixel_loss(states[:, t], decoder(z))      # main.py:188-190
+            if a.truncate_bptt and t > 1:
+                z = z.detach()
+            rec_loss = torch.mean(rec_loss_batch * active_mask)
+            ts.collect('Reconstruction t={}'.format(t), rec_loss)
+            loss += rec_loss                                                   # main.py:197
+
+            z = transition(z, onehots[:, t])                                   # main.py:206-215
+
+            if a.latent_overshooting:
+                # main.py:217-230 (structure kept, incl. its index quirks)
+                lo_z_set[t] = encoder(states[:, t - 1:t + 2])
+                for t_left in range(1, t):
+                    lo_z_set[t_left] = transition(lo_z_set[t_left], onehots[:, t - 1])
+                for t_a in range(2, t - 1):
+                    lo_loss_batch = latent_state_loss(lo_z_set[t].detach(), lo_z_set[t_a])
+                    lo_loss += a.td_lambda * torch.mean(lo_loss_batch * active_mask)
+
+        if a.latent_overshooting:
+            ts.collect('LO total', lo_loss)
+            loss += theta * lo_loss
+
+        if enable_cf_shuffle_loss:
+            # main.py:242-262; z_cf_b aliases z_orig and is mutated in place there
+            z_cf_a = z.clone()
+            z_cf_b = z_orig
+            unswapped_factor_map = torch.ones((batch_size, latent_dim), device=states.device)
+            for i in range(batch_size):
+                idx_a = np.random.randint(latent_dim)
+                idx_b = np.random.randint(latent_dim)
+                unswapped_factor_map[i, idx_a] = 0
+                unswapped_factor_map[i, idx_b] = 0
+                z_cf_b[i, idx_a], z_cf_b[i, idx_b] = z_cf_b[i, idx_b], z_cf_b[i, idx_a]
+            for t in range(1, a.counterfactual_horizon):
+                z_cf_b = transition(z_cf_b, onehots[:, t])
+            cf_loss = torch.abs(z_cf_a - z_cf_b).mean(-1).mean(-1) * unswapped_factor_map
+            cf_loss = CF_REGULARIZATION_LAMBDA * torch.mean(cf_loss.mean(-1) * active_mask)
+            loss += cf_loss
+            ts.collect('CF Disentanglement Loss', cf_loss)
+
+        if enable_control_bias_loss:
+            # main.py:268-283
+            z_cf_a = z.clone()
+            z_cf_b = z_orig
+            cf_actions = np.array(actions).copy()
+            np.random.shuffle(cf_actions)
+            cf_onehots = onehot(cf_actions, self.num_actions)
+            for t in range(1, a.counterfactual_horizon):
+                z_cf_b = transition(z_cf_b, cf_onehots[:, t])
+            eps = .001
+            cf_loss = -torch.log(torch.abs(z_cf_a - z_cf_b).mean(-1).mean(-1).mean(-1) + eps)
+            cf_loss = CF_REGULARIZATION_LAMBDA * torch.mean(cf_loss * active_mask)
+            loss += cf_loss
+            ts.collect('CF Control Bias Loss', cf_loss)
+
+        loss.backward()                                                        # main.py:285
+
+        if self.world > 1:
+            for f in self.flats:
+                f.all_reduce()      # sum over ranks; AdamClip applies 1/world before the clip
+
+        self.opt_pred.step()                                                   # main.py:292-296
+        if not a.finetune_reward:
+            self.opt_enc.step()
+            self.opt_dec.step()
+            self.opt_trans.step()
+        return loss.detach()
+
+
 def train(latent_dim, datasource, num_actions, num_rewards,
           encoder, decoder, reward_predictor, discriminator, transition):
     """main.py:106-299."""
     batch_size = args.batch_size
     train_iters = args.train_iters
-    td_lambda_coef = args.td_lambda
-    truncate_bptt = args.truncate_bptt
-    enable_latent_overshooting = args.latent_overshooting
-    learning_rate = args.learning_rate
-    min_prediction_horizon = args.horizon_min
-    max_prediction_horizon = args.horizon_max
-    REWARD_COEF = args.reward_coef
-    counterfactual_horizon = args.counterfactual_horizon
-    start_iter = args.start_iter
-    enable_cf_shuffle_loss = args.enable_disentanglement_loss
-    enable_control_bias_loss = args.enable_action_control_loss
-    rank, world = _dist()
-
-    # main.py:125-129 + 287-290: clip 0.1 on enc/trans/dec, none on the reward head;
-    # the discriminator's optimizer is created but never stepped in the reference.
-    opt_enc = AdamClip(encoder.parameters(), lr=learning_rate, clip_value=0.1)
-    opt_dec = AdamClip(decoder.parameters(), lr=learning_rate, clip_value=0.1)
-    opt_trans = AdamClip(transition.parameters(), lr=learning_rate, clip_value=0.1)
-    opt_disc = AdamClip(discriminator.parameters(), lr=learning_rate)      # noqa: F841
-    opt_pred = AdamClip(reward_predictor.parameters(), lr=learning_rate)
-    flats = [_FlatGrads(m) for m in (encoder, decoder, transition, reward_predictor)]
-    for o in (opt_enc, opt_dec, opt_trans, opt_pred):
-        o.grad_scale = 1.0 / world
-    ts = TimeSeries('Training Model', train_iters, tensorboard=True)
-
-    for train_iter in range(start_iter, train_iters + 1):
+    trainer = Trainer(latent_dim, num_actions, num_rewards, encoder, decoder, reward_predictor, discriminator,
+                      transition)
+    rank = trainer.rank
+    ts = trainer.ts
+    for train_iter in range(args.start_iter, train_iters + 1):
         if train_iter % args.eval_every == 0:
             if rank == 0:
                 print('Evaluating networks...')
@@ -187,104 +294,13 @@ def train(latent_dim, datasource, num_actions, num_rewards,
                 torch.save(discriminator.state_dict(), 'model-discriminator.pth')
                 torch.save(reward_predictor.state_dict(), 'model-reward_predictor.pth')
 
-        theta = train_iter / train_iters
-        pred_delta = max_prediction_horizon - min_prediction_horizon
-        prediction_horizon = min_prediction_horizon + int(pred_delta * theta)
-
-        train_mode([encoder, decoder, transition, discriminator, reward_predictor])
-        for f in flats:
-            f.zero()
+        theta = train_iter / train_iters                                       # main.py:143-145
+        pred_delta = args.horizon_max - args.horizon_min
+        prediction_horizon = args.horizon_min + int(pred_delta * theta)
 
         states, rewards, dones, actions = datasource.get_trajectories(batch_size, prediction_horizon)
-        states = _upload(states)
-        rewards = _upload(rewards)
-        dones = _upload(np.asarray(dones).astype(int))
-        onehots = onehot(actions, num_actions)          # (B, T, A) built once per iteration
-
-        z = encoder(states[:, 0:3])
-        z_orig = z.clone()
-        active_mask = torch.ones(batch_size, device=_device())
-
-        loss = 0
-        lo_loss = 0
-        lo_z_set = {}
-        for t in range(1, prediction_horizon - 1):
-            active_mask = active_mask * (1 - dones[:, t])
-
-            expected_reward = reward_predictor(z)
-            actual_reward = rewards[:, t]
-            reward_difference = torch.mean(torch.mean((expected_reward - actual_reward) ** 2, dim=1) * active_mask)
-            ts.collect('Rd Loss t={}'.format(t), reward_difference)
-            loss += theta * REWARD_COEF * reward_difference
-
-            target_pixels = states[:, t]
-            rec_loss_batch = decoder_pixel_loss(target_pixels, decoder(z))
-            if truncate_bptt and t > 1:
-                z = z.detach()
-            rec_loss = torch.mean(rec_loss_batch * active_mask)
-            ts.collect('Reconstruction t={}'.format(t), rec_loss)
-            loss += rec_loss
-
-            new_z = transition(z, onehots[:, t])
-            z = new_z
-
-            if enable_latent_overshooting:
-                # main.py:217-230 (kept verbatim in structure, incl. its index quirks)
-                lo_z_set[t] = encoder(states[:, t - 1:t + 2])
-                for t_left in range(1, t):
-                    lo_z_set[t_left] = transition(lo_z_set[t_left], onehots[:, t - 1])
-                for t_a in range(2, t - 1):
-                    lo_loss_batch = latent_state_loss(lo_z_set[t].detach(), lo_z_set[t_a])
-                    lo_loss += td_lambda_coef * torch.mean(lo_loss_batch * active_mask)
-
-        if enable_latent_overshooting:
-            ts.collect('LO total', lo_loss)
-            loss += theta * lo_loss
-
-        if enable_cf_shuffle_loss and train_iter % CF_REGULARIZATION_RATE == 0:
-            # main.py:242-262; z_cf_b aliases z_orig and is mutated in place there
-            z_cf_a = z.clone()
-            z_cf_b = z_orig
-            unswapped_factor_map = torch.ones((batch_size, latent_dim), device=_device())
-            for i in range(batch_size):
-                idx_a = np.random.randint(latent_dim)
-                idx_b = np.random.randint(latent_dim)
-                unswapped_factor_map[i, idx_a] = 0
-                unswapped_factor_map[i, idx_b] = 0
-                z_cf_b[i, idx_a], z_cf_b[i, idx_b] = z_cf_b[i, idx_b], z_cf_b[i, idx_a]
-            for t in range(1, counterfactual_horizon):
-                z_cf_b = transition(z_cf_b, onehots[:, t])
-            cf_loss = torch.abs(z_cf_a - z_cf_b).mean(-1).mean(-1) * unswapped_factor_map
-            cf_loss = CF_REGULARIZATION_LAMBDA * torch.mean(cf_loss.mean(-1) * active_mask)
-            loss += cf_loss
-            ts.collect('CF Disentanglement Loss', cf_loss)
-
-        if enable_control_bias_loss and train_iter % CF_REGULARIZATION_RATE == 0:
-            # main.py:268-283
-            z_cf_a = z.clone()
-            z_cf_b = z_orig
-            cf_actions = actions.copy()
-            np.random.shuffle(cf_actions)
-            cf_onehots = onehot(cf_actions, num_actions)
-            for t in range(1, counterfactual_horizon):
-                z_cf_b = transition(z_cf_b, cf_onehots[:, t])
-            eps = .001
-            cf_loss = -torch.log(torch.abs(z_cf_a - z_cf_b).mean(-1).mean(-1).mean(-1) + eps)
-            cf_loss = CF_REGULARIZATION_LAMBDA * torch.mean(cf_loss * active_mask)
-            loss += cf_loss
-            ts.collect('CF Control Bias Loss', cf_loss)
-
-        loss.backward()
-
-        if world > 1:
-            for f in flats:
-                f.all_reduce()          # sum over ranks; AdamClip applies 1/world before the clip
-
-        opt_pred.step()
-        if not args.finetune_reward:
-            opt_enc.step()
-            opt_dec.step()
-            opt_trans.step()
+        trainer.step(_upload(states), _upload(rewards), _upload(np.asarray(dones).astype(int)),
+                     onehot(actions, num_actions), theta, train_iter, actions)
         if rank == 0:
             ts.print_every(args.log_every)
     if rank == 0:

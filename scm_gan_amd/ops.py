@@ -60,6 +60,36 @@ def pack_conv3x3(weight, cin, cout, transposed=False, cin_total=0, ci0=0):
     return fp, dp
 
 
+class KernelTimer(object):
+    """Optional HIP-event bracket around kernel launches (bench.py roofline):
+    events are recorded on the stream the kernels are launched on."""
+
+    def __init__(self):
+        self.records = []
+
+    def bracket(self, tag, flops):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.records.append((tag, flops, s, e))
+        return s, e
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for tag, flops, s, e in self.records:
+            t = out.setdefault(tag, {"launches": 0, "ms": 0.0, "flops": 0.0})
+            t["launches"] += 1
+            t["ms"] += s.elapsed_time(e)
+            t["flops"] += flops
+        return out
+
+
+kernel_timer = None     # set to a KernelTimer() to time the MFMA conv launches
+
+
+def conv_kernel_name(cout):
+    return "conv3x3_mfma_kernel<%s>" % ("4,2" if cout > 64 else ("2,4" if cout > 32 else "1,4"))
+
+
 def _conv3x3_raw(x1, x2, gate1, gate2, gate_act, wpack, cout, scale, bias, sbias, co1, pad, act):
     lib = L.lib()
     B, c1, H, W = x1.shape
@@ -68,7 +98,12 @@ def _conv3x3_raw(x1, x2, gate1, gate2, gate_act, wpack, cout, scale, bias, sbias
     y2 = _new(x1, B, cout - co1, H, W) if co1 < cout else None
     d = L.ConvDesc(_p(x1), _p(x2), c1, c2, _p(gate1), _p(gate2), gate_act, _p(wpack), cout, _p(scale), _p(bias),
                    _p(sbias), _p(y1), _p(y2), co1, B, H, W, pad, act)
+    if kernel_timer is not None:
+        ev = kernel_timer.bracket(conv_kernel_name(cout), 2.0 * B * H * W * cout * (c1 + c2) * 9)
+        ev[0].record()
     L.check(lib.scm_conv3x3(ctypes.byref(d), _stream()), "scm_conv3x3")
+    if kernel_timer is not None:
+        ev[1].record()
     return y1, y2
 
 

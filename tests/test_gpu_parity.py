@@ -153,3 +153,56 @@ def test_operators_vs_golden(M):
     (yc * dev(fx["cc_gy"])).sum().backward()
     check(fx, "cc_grad_x", xc.grad, ATOL)
     check(fx, "cc_grad.conv.weight", cc.conv.weight.grad, 5e-4, 1e-4)
+
+
+def test_train_and_rollout_vs_reference_run(M, tmp_path, monkeypatch):
+    """scm_gan_amd.main.train() + measure_prediction_mse() against the reference's
+    own main.train() / measure_prediction_mse() run (3 iterations, B=4, 16x16,
+    same data, same recorded Bernoulli noise)."""
+    from scm_gan_amd import main as T
+    from scm_gan_amd.datasource import SyntheticDatasource
+    monkeypatch.chdir(tmp_path)
+    fx = load("train_rollout.npz")
+    B, H, W, horizon, iters, A, R, C, L, seed = [int(v) for v in fx["cfg"]]
+    enc, dec, rp, disc, tr = M.Encoder(L, C), M.Decoder(L, C), M.RewardPredictor(L, R), M.Discriminator(), \
+        M.Transition(L, A)
+    enc.load_state_dict(WS.to_torch(WS.encoder_state(seed)))
+    tr.load_state_dict(WS.to_torch(WS.transition_state(seed + 1)))
+    dec.load_state_dict(WS.to_torch(WS.decoder_state(seed + 2)))
+    rp.load_state_dict(WS.to_torch(WS.reward_state(seed + 3)))
+    disc.load_state_dict(WS.to_torch(WS.discriminator_state(seed + 4)))
+    nrng = np.random.default_rng(5000 + seed)
+    tr.set_noise([dev(nrng.random((B, L, H, W), dtype=np.float32)) for _ in range(iters * (horizon - 2))])
+    ds = SyntheticDatasource(seed=seed, height=H, width=W, channels=C, num_actions=A, num_rewards=R, done_every=4)
+    T.args = T.parser.parse_args(["--batch-size", str(B), "--train-iters", str(iters), "--horizon-min", str(horizon),
+                                  "--horizon-max", str(horizon), "--eval-every", "1000000"])
+    ts = T.train(L, ds, A, R, enc, dec, rp, disc, tr)
+    got = []
+    for it in range(iters):
+        for t in range(1, horizon - 1):
+            got.append(ts.values("Rd Loss t=%d" % t)[it])
+            got.append(ts.values("Reconstruction t=%d" % t)[it])
+    got = np.array(got)
+    assert np.allclose(got, fx["train_loss_values"], atol=2e-4, rtol=2e-4), np.abs(got - fx["train_loss_values"]).max()
+    for name, m in (("enc", enc), ("tr", tr), ("dec", dec), ("rp", rp)):
+        for k, v in m.state_dict().items():
+            if not v.dtype.is_floating_point:
+                continue
+            e = fx["final.%s.%s" % (name, k)]
+            d = WS.digest(v.detach().cpu().numpy())
+            err = np.abs(d[3:] - e[3:])
+            # Adam moves a weight by ~lr=1e-4 per step whatever |g|: a sign flip of a ~0 gradient is 2e-4/step
+            assert np.mean(err < 5e-6) > 0.97 and err.max() < 7e-4, (name, k, err.max(), np.mean(err < 5e-6))
+    T.test_mode([enc, dec, tr, disc, rp])
+    ds_eval = SyntheticDatasource(seed=seed + 77, height=H, width=W, channels=C, num_actions=A, num_rewards=R)
+    with torch.no_grad():
+        out = T.measure_prediction_mse(ds_eval, enc, dec, tr, rp, train_iter=0, timesteps=12)
+    assert np.allclose(out["pixel"][0], fx["eval_mse_pixel"], atol=1e-4)
+    assert np.allclose(out["pixel"][1], fx["eval_std_pixel"], atol=1e-4)
+    assert np.allclose(out["reward"][0], fx["eval_mse_reward"], rtol=2e-3, atol=1e-3)
+    assert (tmp_path / "mse_pixel_iter_000000.json").exists()
+
+
+def test_smoke_entry():
+    import __graft_entry__ as g
+    g.smoke()
