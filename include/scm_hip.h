@@ -168,8 +168,11 @@ typedef struct scm_conv2d_desc {
 } scm_conv2d_desc;
 
 int scm_conv2d_fwd(const scm_conv2d_desc* d, void* stream);
+/* ws: caller workspace of scm_conv2d_bwd_workspace(B, cin, cout, K) floats (needed when dw != NULL);
+ * the batch is split over workgroups and reduced in a fixed order (reproducible). */
+size_t scm_conv2d_bwd_workspace(int B, int cin, int cout, int K);
 int scm_conv2d_bwd(const scm_conv2d_desc* d, const float* dy, float* dx, float* dw, float* db, int accumulate,
-                   void* stream);
+                   float* ws, void* stream);
 
 /* ------------------------------------------------------------------------
  * Bandwidth-bound pieces.

@@ -86,7 +86,8 @@ def lib():
             "scm_sn_power_iter": [ci, vp, ci, vp],
             "scm_sn_fold_grad": [vp, vp, vp, vp, vp, ci, ci, ci, vp, vp],
             "scm_conv2d_fwd": [vp, vp],
-            "scm_conv2d_bwd": [vp, vp, vp, vp, vp, ci, vp],
+            "scm_conv2d_bwd": [vp, vp, vp, vp, vp, ci, vp, vp],
+            "scm_conv2d_bwd_workspace": [ci, ci, ci, ci],
             "scm_bernoulli": [vp, vp, vp, st, ci, u64, u64, vp],
             "scm_factor_sum": [vp, vp, ci, ci, ci, ci, vp],
             "scm_factor_bcast": [vp, vp, ci, ci, ci, ci, vp],
@@ -104,8 +105,8 @@ def lib():
         for name, args in sigs.items():
             fn = getattr(L, name)      # raises AttributeError when the library lacks a declared symbol
             fn.argtypes = args
-            if name != "scm_conv3x3_pack_floats":
-                fn.restype = ctypes.c_int
+            fn.restype = ctypes.c_size_t if name in ("scm_conv3x3_pack_floats", "scm_conv2d_bwd_workspace") \
+                else ctypes.c_int
         L._scm_symbols = sorted(sigs) + ["scm_version", "scm_last_error"]
         _lib = L
     return _lib

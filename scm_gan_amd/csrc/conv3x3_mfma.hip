@@ -33,22 +33,33 @@ struct ConvKArgs {
     int tiles_per_img; int plane;
 };
 
-template <int CT, int PT>
-__global__ void __launch_bounds__(256, 2) conv3x3_mfma_kernel(const ConvKArgs a) {
+// One wave per SIMD with the whole 512-register budget (__launch_bounds__(256, 1)):
+// CT*PT accumulator tiles (256 VGPRs at 4x4) plus the prefetch registers of the
+// next K chunk.  Per chunk:
+//   barrier | registers -> LDS (masks, act' gate applied here) | barrier |
+//   issue the next chunk's global loads into registers | 36 x CT*PT MFMAs
+// Every global load is unconditional on a clamped address (a load under a
+// per-lane condition makes hipcc branch around it and serialise the loads).
+template <int CT, int PT, int NJ, bool GATED>
+__global__ void __launch_bounds__(256, 1) conv3x3_mfma_kernel(const ConvKArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int CW = CT * 32;
     constexpr int WCHUNK = KC * 9 * CW;
+    constexpr int W4 = WCHUNK / 4;                 // float4 per weight chunk
+    constexpr int WR = (W4 + 255) / 256;           // float4 per thread
+    constexpr int PER_CI4 = 9 * CW / 4;
     constexpr int NPW = PT * 32, NP = 4 * NPW;
-    constexpr int TAP_UNROLL = CT == 4 ? 9 : 1;
+    constexpr int PLANE = NJ * 256;                // fixed LDS plane pitch: every thread writes NJ slots, no branches
+    constexpr int WLDS = WR * 256 * 4;             // weight region padded to whole thread passes
     float* wl = smem;
-    float* xl = smem + WCHUNK;
+    float* xl = smem + WLDS;
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lh = lane >> 5;
     const int W = a.W, H = a.H, HW = H * W;
     const int ROWPL = W + 2;
-    const int PLANE = a.plane;
 
     const int b = blockIdx.x / a.tiles_per_img;
     const int tile = blockIdx.x - b * a.tiles_per_img;
@@ -60,24 +71,29 @@ __global__ void __launch_bounds__(256, 2) conv3x3_mfma_kernel(const ConvKArgs a)
     const int nrows = (plast - 1) / W - r0 + 3;
     const int nelem = nrows * ROWPL;
 
-    // staging map: LDS element e = tid + 256*j  <-  plane offset goff[j]
-    // (-1: zero fill, -2: not mine)
-    int goff[MAXJ];
+    // staging map: LDS element e = tid + 256*j  <-  plane offset goff[j] (clamped);
+    // bit j of okmask: a real (or wrapped) pixel; other elements are written as 0
+    int goff[NJ];
+    unsigned okmask = 0u;
 #pragma unroll
-    for (int j = 0; j < MAXJ; ++j) {
+    for (int j = 0; j < NJ; ++j) {
         const int e = tid + 256 * j;
-        int g = -2;
+        int g = 0;
         if (e < nelem) {
             const int r = e / ROWPL;
             const int c = e - r * ROWPL;
             int iy = r0 - 1 + r, ix = c - 1;
+            bool ok = true;
             if (a.pad_mode == SCM_PAD_CIRCULAR) {
                 iy = iy < 0 ? iy + H : (iy >= H ? iy - H : iy);
                 ix = ix < 0 ? ix + W : (ix >= W ? ix - W : ix);
-                g = iy * W + ix;
             } else {
-                g = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? iy * W + ix : -1;
+                ok = (iy >= 0 && iy < H && ix >= 0 && ix < W);
             }
+            iy = iy < 0 ? 0 : (iy >= H ? H - 1 : iy);
+            ix = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
+            g = iy * W + ix;
+            if (ok) okmask |= 1u << j;
         }
         goff[j] = g;
     }
@@ -101,60 +117,69 @@ __global__ void __launch_bounds__(256, 2) conv3x3_mfma_kernel(const ConvKArgs a)
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
     const int cin = a.c1 + a.c2;
-    const float* wsrc = a.wpack + (size_t)cg * cin * 9 * CW;
-    const int gate_act = a.gate_act;
+    const f32x4* wsrc4 = reinterpret_cast<const f32x4*>(a.wpack + (size_t)cg * cin * 9 * CW);
+    const int wtotal4 = cin * PER_CI4;
+    const int gate_act = GATED ? a.gate_act : 0;
 
-    for (int ci0 = 0; ci0 < cin; ci0 += KC) {
-        // ---- stage weights: contiguous [KC][9][32][CT] slab
-        {
-            const f32x4* src4 = reinterpret_cast<const f32x4*>(wsrc + (size_t)ci0 * 9 * CW);
-            f32x4* dst4 = reinterpret_cast<f32x4*>(wl);
-            constexpr int PER_CI4 = 9 * CW / 4;
+    float pw[WR][4];      // plain floats: an ext_vector array captured by the lambdas lands in scratch
+    float px[KC][NJ], pg[KC][NJ];
+
+    auto fetch = [&](int ci0) {
 #pragma unroll
-            for (int k = 0; k < (WCHUNK / 4 + 255) / 256; ++k) {
-                const int i = tid + 256 * k;
-                if (i < WCHUNK / 4) {
-                    const int cil = i / PER_CI4;
-                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                    if (ci0 + cil < cin) v = src4[i];
-                    dst4[i] = v;
-                }
-            }
+        for (int k = 0; k < WR; ++k) {
+            int gi = ci0 * PER_CI4 + tid + 256 * k;
+            gi = gi < wtotal4 ? gi : wtotal4 - 1;
+            const f32x4 t = wsrc4[gi];
+            pw[k][0] = t[0]; pw[k][1] = t[1]; pw[k][2] = t[2]; pw[k][3] = t[3];
         }
-        // ---- stage halo tile of KC input planes
 #pragma unroll
         for (int c = 0; c < KC; ++c) {
             const int ci = ci0 + c;
-            const float* src = nullptr;
-            const float* gsrc = nullptr;
-            if (ci < cin) {
-                if (ci < a.c1) {
-                    const size_t o = ((size_t)b * a.c1 + ci) * HW;
-                    src = a.x1 + o;
-                    if (gate_act) gsrc = a.gate1 + o;
-                } else {
-                    const size_t o = ((size_t)b * a.c2 + (ci - a.c1)) * HW;
-                    src = a.x2 + o;
-                    if (gate_act) gsrc = a.gate2 + o;
-                }
-            }
+            const int cc = ci < cin ? ci : 0;
+            const bool first = cc < a.c1;
+            const size_t o = first ? ((size_t)b * a.c1 + cc) * HW : ((size_t)b * a.c2 + (cc - a.c1)) * HW;
+            const float* src = (first ? a.x1 : a.x2) + o;
 #pragma unroll
-            for (int j = 0; j < MAXJ; ++j) {
-                const int g = goff[j];
-                if (g != -2) {
-                    float v = 0.f;
-                    if (src != nullptr && g >= 0) {
-                        v = src[g];
-                        if (gate_act) v *= scm_act_grad_from_out(gsrc[g], gate_act);
-                    }
-                    xl[c * PLANE + tid + 256 * j] = v;
-                }
+            for (int j = 0; j < NJ; ++j) px[c][j] = src[goff[j]];
+            if constexpr (GATED) {
+                const float* gsrc = (first ? a.gate1 : a.gate2) + o;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) pg[c][j] = gsrc[goff[j]];
             }
         }
+    };
+    auto store = [&](int ci0) {
+#pragma unroll
+        for (int k = 0; k < WR; ++k) {
+            const int i = tid + 256 * k;
+            const int cil = i / PER_CI4;
+            const bool wv = ci0 + cil < cin;
+            f32x4 v;
+            v[0] = wv ? pw[k][0] : 0.f; v[1] = wv ? pw[k][1] : 0.f;
+            v[2] = wv ? pw[k][2] : 0.f; v[3] = wv ? pw[k][3] : 0.f;
+            reinterpret_cast<f32x4*>(wl)[i] = v;
+        }
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            const bool cvalid = ci0 + c < cin;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                float v = px[c][j];
+                if constexpr (GATED) v *= scm_act_grad_from_out(pg[c][j], gate_act);
+                xl[c * PLANE + tid + 256 * j] = (cvalid && (okmask & (1u << j))) ? v : 0.f;
+            }
+        }
+    };
+
+    fetch(0);
+    for (int ci0 = 0; ci0 < cin; ci0 += KC) {
+        __syncthreads();                 // the previous chunk's MFMAs are done with the tiles
+        store(ci0);
         __syncthreads();
+        if (ci0 + KC < cin) fetch(ci0 + KC);   // flies under this chunk's MFMAs
 
         // ---- MFMA over the chunk: 9 taps x KC/2 k-steps
-#pragma unroll TAP_UNROLL
+#pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int toff = (tap / 3) * ROWPL + (tap % 3);
 #pragma unroll
@@ -180,7 +205,6 @@ __global__ void __launch_bounds__(256, 2) conv3x3_mfma_kernel(const ConvKArgs a)
                         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[n], acc[m][n], 0, 0, 0);
             }
         }
-        __syncthreads();
     }
 
     // ---- epilogue: scale, bias, per-sample bias, activation, NCHW store
@@ -282,6 +306,29 @@ extern "C" int scm_pack_conv3x3_weights(const float* w, int cin, int cout, int t
     return SCM_OK;
 }
 
+template <int CT, int PT, int NJ, bool GATED>
+static int launch_conv_nj(const ConvKArgs& a, int groups, hipStream_t s) {
+    constexpr int W4 = KC * 9 * CT * 32 / 4, WR = (W4 + 255) / 256;
+    const size_t lds = ((size_t)WR * 256 * 4 + (size_t)KC * NJ * 256) * sizeof(float);
+    auto kern = conv3x3_mfma_kernel<CT, PT, NJ, GATED>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        int rc = scm_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+                               "hipFuncSetAttribute");
+        if (rc) return rc;
+        attr_set = true;
+    }
+    if (lds > 160 * 1024) {
+        scm_set_error("scm_conv3x3: halo tile of %zu bytes exceeds the LDS", lds);
+        return SCM_EUNSUPPORTED;
+    }
+    dim3 grid(a.B * a.tiles_per_img, groups);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+    SCM_LAUNCH_CHECK("conv3x3_mfma_kernel");
+    return SCM_OK;
+}
+
 template <int CT, int PT>
 static int launch_conv(const ConvKArgs& k, int groups, hipStream_t s) {
     constexpr int NP = 128 * PT;
@@ -291,24 +338,14 @@ static int launch_conv(const ConvKArgs& k, int groups, hipStream_t s) {
     int rows = (NP % a.W == 0) ? NP / a.W : (NP + a.W - 2) / a.W + 1;
     if (rows > a.H) rows = a.H;
     a.plane = (rows + 2) * (a.W + 2);
-    if (a.plane > MAXJ * 256) {
-        scm_set_error("scm_conv3x3: image width %d too large for the halo staging map", a.W);
-        return SCM_EUNSUPPORTED;
-    }
-    const size_t lds = ((size_t)KC * 9 * CT * 32 + (size_t)KC * a.plane) * sizeof(float);
-    auto kern = conv3x3_mfma_kernel<CT, PT>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        int rc = scm_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
-                               "hipFuncSetAttribute");
-        if (rc) return rc;
-        attr_set = true;
-    }
-    dim3 grid(a.B * a.tiles_per_img, groups);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
-    SCM_LAUNCH_CHECK("conv3x3_mfma_kernel");
-    return SCM_OK;
+    const bool gated = a.gate_act != 0;
+    if (a.plane <= 4 * 256)
+        return gated ? launch_conv_nj<CT, PT, 4, true>(a, groups, s) : launch_conv_nj<CT, PT, 4, false>(a, groups, s);
+    if (a.plane <= MAXJ * 256)
+        return gated ? launch_conv_nj<CT, PT, MAXJ, true>(a, groups, s)
+                     : launch_conv_nj<CT, PT, MAXJ, false>(a, groups, s);
+    scm_set_error("scm_conv3x3: image width %d too large for the halo staging map", a.W);
+    return SCM_EUNSUPPORTED;
 }
 
 extern "C" int scm_conv3x3(const scm_conv3x3_desc* d, void* stream) {
@@ -336,7 +373,7 @@ extern "C" int scm_conv3x3(const scm_conv3x3_desc* d, void* stream) {
     const int ct = conv_ct(d->cout);
     const int groups = (d->cout + ct * 32 - 1) / (ct * 32);
     hipStream_t s = (hipStream_t)stream;
-    if (ct == 4) return launch_conv<4, 2>(k, groups, s);
+    if (ct == 4) return launch_conv<4, 4>(k, groups, s);
     if (ct == 2) return launch_conv<2, 4>(k, groups, s);
-    return launch_conv<1, 4>(k, groups, s);
+    return launch_conv<1, 8>(k, groups, s);
 }

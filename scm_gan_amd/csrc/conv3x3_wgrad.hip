@@ -28,13 +28,27 @@ struct WgradKArgs {
     int ci_groups;
 };
 
-template <int MT, int NT>
-__global__ void __launch_bounds__(256, 2) conv3x3_wgrad_kernel(const WgradKArgs a) {
+// 4 waves as WM x WN, one wave per SIMD with the whole 512-register budget: wave
+// (wm, wn) owns co tile wm and NTW ci tiles, i.e. 9*NTW accumulator tiles (288
+// VGPRs at NTW = 2) plus the prefetch registers.  Software pipeline per image
+// row y of the band:
+//   barrier | registers -> LDS (x row y+1 into the rolling slot, dyp row y) |
+//   barrier | issue global loads of row y+1's data into registers | 288 MFMAs
+// so the HBM/L2 latency of the next row hides under this row's MFMAs.
+template <int WM, int WN, int NTW>
+__global__ void __launch_bounds__(256, 1) conv3x3_wgrad_kernel(const WgradKArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    static_assert(WM * WN == 4, "4 waves");
+    constexpr int NW = 4;
+    constexpr int MT = WM;                 // co tiles per workgroup
+    constexpr int NT = WN * NTW;           // ci tiles per workgroup
+    constexpr int DR = MT * 32 / NW;       // dy rows staged per wave
+    constexpr int XR = NT * 32 / NW;       // x channels staged per wave
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: keeps bases in SGPRs
     const int l31 = lane & 31, lh = lane >> 5;
-    const int wm = wave / NT, wn = wave % NT;
+    const int wm = wave / WN, wn = wave % WN;
     const int W = a.W, H = a.H, HW = H * W;
     const int PS = a.PS;
     const int PSP = PS + 4;                 // row pitch of the x tile (cols -1 .. PS+2)
@@ -54,88 +68,179 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wgrad_kernel(const WgradKArgs 
     const int co_base = cog * MT * 32, ci_base = cig * NT * 32;
     const int cin = a.c1 + a.c2;
     const bool circ = a.pad_mode == SCM_PAD_CIRCULAR;
+    const int gate_act = a.gate_act;
 
-    f32x16 acc[9];
+    f32x16 acc[NTW][9];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int n = 0; n < NTW; ++n)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[n][t][r] = 0.f;
     float csum = 0.f;
     const bool do_csum = a.csum_part != nullptr && cig == 0 && wn == 0;
 
     const float* ap = dyl + (wm * 32 + l31) * DPL + lh;
-    const float* bp = xl + (wn * 32 + l31) * XPL + lh;
+    const float* bp = xl + (wn * NTW * 32 + l31) * XPL + lh;
+
+    // Every global load below is UNCONDITIONAL on a clamped, always-valid address and
+    // masked afterwards with a select: a load under a per-lane condition makes hipcc
+    // branch around each load and serialise them (cdna guide, "three .s-level traps" (c)).
+    // wave-uniform base of x channel c of this workgroup's ci range (x1 when beyond cin)
+    auto xbase = [&](int c, bool& valid) -> const float* {
+        const int ci = ci_base + c;
+        valid = ci < cin;
+        const int cc = valid ? ci : 0;
+        return cc < a.c1 ? a.x1 + ((size_t)b * a.c1 + cc) * HW : a.x2 + ((size_t)b * a.c2 + (cc - a.c1)) * HW;
+    };
+    // the one halo element of this thread: channel hc, side hs (0: left col, 1: right col)
+    const int hc = tid >> 1, hs = tid & 1;
+    bool hvalid = false;
+    const float* hsrc = xbase(hc < NT * 32 ? hc : 0, hvalid);
+    hvalid = hvalid && hc < NT * 32;
+
+    float pdy[DR], pg[DR], px[XR], phalo = 0.f;
 
     for (int seg = 0; seg < a.nseg; ++seg) {
         const int x0 = seg * PS;
         int ps = W - x0;
         if (ps > PS) ps = PS;
         const int pse = (ps + 1) & ~1;
+
+        // image column of LDS column cc (cc = 0 is x0-1); ok = inside the image (or wrapped)
+        auto img_col = [&](int cc, bool& ok) -> int {
+            int xi = x0 + cc - 1;
+            if (circ) {
+                ok = true;
+                xi = xi < 0 ? xi + W : (xi >= W ? xi - W : xi);
+            } else {
+                ok = (xi >= 0 && xi < W);
+            }
+            return xi < 0 ? 0 : (xi >= W ? W - 1 : xi);
+        };
+        bool ok_main, ok_halo;
+        const int xi_main = img_col(lane + 1, ok_main);     // this lane's interior column
+        ok_main = ok_main && (lane < pse + 1);
+        const int hcc = hs ? pse + 1 : 0;
+        const int xi_halo = img_col(hcc, ok_halo);
+        ok_halo = ok_halo && hvalid;
+
+        // fetch_* only ISSUE loads (raw values stay in registers, nothing consumes them
+        // before the MFMA loop); store_* apply the zero-fill masks and write LDS.
+        auto fetch_xrow = [&](int r) {      // image row r (may be -1 or H) -> px[], phalo
+            int ri = r;
+            if (circ) ri = r < 0 ? r + H : (r >= H ? r - H : r);
+            ri = ri < 0 ? 0 : (ri >= H ? H - 1 : ri);
+            const int ro = ri * W;
+#pragma unroll
+            for (int k = 0; k < XR; ++k) {
+                bool cv;
+                const float* src = xbase(wave * XR + k, cv);
+                px[k] = src[ro + xi_main];
+            }
+            phalo = hsrc[ro + xi_halo];
+        };
+        auto store_xrow = [&](int r) {
+            const int slot = (r + 3) % 3;
+            const bool rvalid = circ || (r >= 0 && r < H);
+            if (lane < pse + 1) {
+#pragma unroll
+                for (int k = 0; k < XR; ++k) {
+                    const bool cv = ci_base + wave * XR + k < cin;
+                    xl[(wave * XR + k) * XPL + slot * PSP + lane + 1] = (cv && rvalid && ok_main) ? px[k] : 0.f;
+                }
+            }
+            if (hc < NT * 32) xl[hc * XPL + slot * PSP + hcc] = (rvalid && ok_halo) ? phalo : 0.f;
+        };
+        const int lane_c = lane < ps ? lane : ps - 1;
+        auto fetch_dy = [&](int y) {
+#pragma unroll
+            for (int k = 0; k < DR; ++k) {
+                const int co = co_base + wave * DR + k;
+                const int coc = co < a.cout ? co : a.cout - 1;
+                const size_t rowo = ((size_t)b * a.cout + coc) * HW + (size_t)y * W + x0;   // wave-uniform
+                pdy[k] = a.dy[rowo + lane_c];
+                pg[k] = gate_act ? a.gate[rowo + lane_c] : 1.f;
+            }
+        };
+        auto store_dy = [&]() {      // mask + act' multiply happen here, after the MFMAs that hid the loads
+            if (lane < pse) {
+#pragma unroll
+                for (int k = 0; k < DR; ++k) {
+                    const bool ok = co_base + wave * DR + k < a.cout && lane < ps;
+                    const float v = gate_act ? pdy[k] * scm_act_grad_from_out(pg[k], gate_act) : pdy[k];
+                    dyl[(wave * DR + k) * DPL + lane] = ok ? v : 0.f;
+                }
+            }
+        };
+
+        // ---- prologue of the band: rows y_begin-1 and y_begin go straight to LDS
+        __syncthreads();
+        fetch_xrow(y_begin - 1);
+        store_xrow(y_begin - 1);
+        fetch_xrow(y_begin);
+        store_xrow(y_begin);
+        fetch_xrow(y_begin + 1);
+        fetch_dy(y_begin);
+
         for (int y = y_begin; y < y_end; ++y) {
+            __syncthreads();                 // previous row's MFMAs are done with the tiles
+            store_xrow(y + 1);
+            store_dy();
             __syncthreads();
-            // ---- x halo rows: all three on the first row of a band, then only row y+1
-            for (int rr = (y == y_begin ? -1 : 1); rr <= 1; ++rr) {
-                const int r = y + rr;
-                const int slot = (r + 3) % 3;
-                int ri = r;
-                bool rvalid = true;
-                if (circ) ri = r < 0 ? r + H : (r >= H ? r - H : r);
-                else rvalid = (r >= 0 && r < H);
-                for (int c = wave; c < NT * 32; c += 4) {
-                    const int ci = ci_base + c;
-                    const float* src = nullptr;
-                    if (ci < cin && rvalid)
-                        src = ci < a.c1 ? a.x1 + ((size_t)b * a.c1 + ci) * HW + (size_t)ri * W
-                                        : a.x2 + ((size_t)b * a.c2 + (ci - a.c1)) * HW + (size_t)ri * W;
-                    float* dst = xl + c * XPL + slot * PSP;
-                    for (int cc = lane; cc < pse + 2; cc += 64) {
-                        int xi = x0 + cc - 1;
-                        bool v = src != nullptr;
-                        if (circ) xi = xi < 0 ? xi + W : (xi >= W ? xi - W : xi);
-                        else v = v && xi >= 0 && xi < W;
-                        dst[cc] = v ? src[xi] : 0.f;
-                    }
-                }
+            if (y + 1 < y_end) {             // next row's loads fly under this row's MFMAs
+                fetch_xrow(y + 2);
+                fetch_dy(y + 1);
             }
-            // ---- dyp row tile
-            for (int c = wave; c < MT * 32; c += 4) {
-                const int co = co_base + c;
-                float v = 0.f;
-                if (co < a.cout && lane < ps) {
-                    const size_t o = ((size_t)b * a.cout + co) * HW + (size_t)y * W + x0 + lane;
-                    v = a.dy[o];
-                    if (a.gate_act) v *= scm_act_grad_from_out(a.gate[o], a.gate_act);
-                }
-                if (lane < pse) dyl[c * DPL + lane] = v;
-            }
-            __syncthreads();
-            // ---- MFMA: k = pixel pairs of this row segment
             const int ro0 = ((y + 2) % 3) * PSP, ro1 = (y % 3) * PSP, ro2 = ((y + 1) % 3) * PSP;
             const int nks = pse >> 1;
-            for (int ks = 0; ks < nks; ++ks) {
-                const float av = ap[2 * ks];
-                if (do_csum) csum += av;
-                const float* q = bp + 2 * ks;
-                float bv[9];
-                bv[0] = q[ro0]; bv[1] = q[ro0 + 1]; bv[2] = q[ro0 + 2];
-                bv[3] = q[ro1]; bv[4] = q[ro1 + 1]; bv[5] = q[ro1 + 2];
-                bv[6] = q[ro2]; bv[7] = q[ro2 + 1]; bv[8] = q[ro2 + 2];
+            // explicit register double-buffer of the LDS operands: with one wave per SIMD
+            // nothing else hides the ds_read latency, so k-step s+1's reads are issued
+            // before k-step s's 9*NTW MFMAs.
+            auto lds_k = [&](int ks, float& av, float (&bv)[NTW][9]) {
+                av = ap[2 * ks];
 #pragma unroll
-                for (int t = 0; t < 9; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[t], 0, 0, 0);
+                for (int n = 0; n < NTW; ++n) {
+                    const float* q = bp + n * 32 * XPL + 2 * ks;
+                    bv[n][0] = q[ro0]; bv[n][1] = q[ro0 + 1]; bv[n][2] = q[ro0 + 2];
+                    bv[n][3] = q[ro1]; bv[n][4] = q[ro1 + 1]; bv[n][5] = q[ro1 + 2];
+                    bv[n][6] = q[ro2]; bv[n][7] = q[ro2 + 1]; bv[n][8] = q[ro2 + 2];
+                }
+            };
+            auto mfma_k = [&](float av, const float (&bv)[NTW][9]) {
+                if (do_csum) csum += av;
+#pragma unroll
+                for (int n = 0; n < NTW; ++n)
+#pragma unroll
+                    for (int t = 0; t < 9; ++t)
+                        acc[n][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[n][t], acc[n][t], 0, 0, 0);
+            };
+            float av0, av1, bv0[NTW][9], bv1[NTW][9];
+            lds_k(0, av0, bv0);
+#pragma unroll 1
+            for (int ks = 0; ks < nks; ks += 2) {
+                const int k1 = ks + 1 < nks ? ks + 1 : nks - 1;
+                lds_k(k1, av1, bv1);
+                mfma_k(av0, bv0);
+                const int k2 = ks + 2 < nks ? ks + 2 : nks - 1;
+                lds_k(k2, av0, bv0);
+                if (ks + 1 < nks) mfma_k(av1, bv1);
             }
         }
     }
 
     // ---- partial slab part[split][tap][co][ci]
-    const int ci = ci_base + wn * 32 + l31;
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
+    for (int n = 0; n < NTW; ++n) {
+        const int ci = ci_base + (wn * NTW + n) * 32 + l31;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = co_base + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (co < a.cout && ci < cin)
-                a.part[(((size_t)split * 9 + t) * a.cout + co) * cin + ci] = acc[t][r];
+        for (int t = 0; t < 9; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co_base + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (co < a.cout && ci < cin)
+                    a.part[(((size_t)split * 9 + t) * a.cout + co) * cin + ci] = acc[n][t][r];
+            }
         }
     }
     if (a.csum_part != nullptr && cig == 0 && wn == 0) {
@@ -156,26 +261,46 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, 
     const int t = idx / per_tap;
     const int rem = idx - t * per_tap;
     const int co = rem / cin, ci = rem - co * cin;
-    float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += part[(size_t)k * 9 * per_tap + idx];
+    // 8 independent partial sums keep 8 slab loads in flight; fixed order -> reproducible
+    float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const size_t stride = (size_t)9 * per_tap;
+    int k = 0;
+    for (; k + 8 <= nsplit; k += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s8[j] += part[(size_t)(k + j) * stride + idx];
+    }
+    for (; k < nsplit; ++k) s8[0] += part[(size_t)k * stride + idx];
+    const float s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
     const size_t o = transposed_dst ? ((size_t)(dc0 + ci) * cout + co) * 9 + (8 - t)
                                     : ((size_t)co * dct + dc0 + ci) * 9 + t;
     dw[o] = accumulate ? dw[o] + s : s;
 }
 
-// csum[b][co] = sum over the image's splits; db[co] = sum_b csum[b][co]
-__global__ void csum_reduce_kernel(const float* __restrict__ csum_part, int B, int spi, int cout,
-                                   int accumulate, float* __restrict__ csum, float* __restrict__ db) {
-    const int co = blockIdx.x * blockDim.x + threadIdx.x;
-    if (co >= cout) return;
+// csum[b][co] = sum over the image's splits; db[co] = sum_b csum[b][co].
+// block = 64 co x 16 batch lanes; the 16 lanes' partial db sums meet in LDS.
+__global__ void __launch_bounds__(1024) csum_reduce_kernel(const float* __restrict__ csum_part, int B, int spi,
+                                                           int cout, int accumulate, float* __restrict__ csum,
+                                                           float* __restrict__ db) {
+    __shared__ float red[16][64];
+    const int cl = threadIdx.x & 63, bl = threadIdx.x >> 6;
+    const int co = blockIdx.x * 64 + cl;
     float tot = 0.f;
-    for (int b = 0; b < B; ++b) {
-        float s = 0.f;
-        for (int k = 0; k < spi; ++k) s += csum_part[((size_t)b * spi + k) * cout + co];
-        if (csum) csum[(size_t)b * cout + co] = s;
-        tot += s;
+    if (co < cout) {
+        for (int b = bl; b < B; b += 16) {
+            float s = 0.f;
+            for (int k = 0; k < spi; ++k) s += csum_part[((size_t)b * spi + k) * cout + co];
+            if (csum) csum[(size_t)b * cout + co] = s;
+            tot += s;
+        }
     }
-    if (db) db[co] = accumulate ? db[co] + tot : tot;
+    red[bl][cl] = tot;
+    __syncthreads();
+    if (bl == 0 && co < cout && db) {
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) t += red[j][cl];
+        db[co] = accumulate ? db[co] + t : t;
+    }
 }
 
 // ------------------------------------------------------------------ host
@@ -185,15 +310,16 @@ struct WgradPlan {
 
 static int wgrad_plan(int B, int H, int W, int cin, int cout, WgradPlan* p) {
     const int cot = (cout + 31) / 32, cit = (cin + 31) / 32;
-    if (cot >= 4 || cit == 1) { p->mt = 4; p->nt = 1; }
-    else if (cot >= 2) { p->mt = 2; p->nt = 2; }
-    else { p->mt = 1; p->nt = 4; }
+    if (cot >= 3) { p->mt = 4; p->nt = 2; }          // 128 co x 64 ci per workgroup
+    else if (cot == 2) { p->mt = 2; p->nt = 4; }     //  64 co x 128 ci
+    else { p->mt = 1; p->nt = 4; }                   //  32 co x 128 ci
     p->co_groups = (cot + p->mt - 1) / p->mt;
     p->ci_groups = (cit + p->nt - 1) / p->nt;
     p->nseg = (W + 63) / 64;
     p->PS = (W + p->nseg - 1) / p->nseg;
     const int groups = p->co_groups * p->ci_groups;
-    int spi = (768 + B * groups - 1) / (B * groups);
+    // one workgroup per CU fills the chip (8 waves = 2 per SIMD): aim at ~256 workgroups
+    int spi = (256 + B * groups - 1) / (B * groups);
     if (spi < 1) spi = 1;
     if (spi > H) spi = H;
     p->rows_per_split = (H + spi - 1) / spi;
@@ -212,11 +338,12 @@ extern "C" int scm_conv3x3_wgrad_workspace(int B, int H, int W, int cin, int cou
     return SCM_OK;
 }
 
-template <int MT, int NT>
+template <int WM, int WN, int NTW>
 static int launch_wgrad(const WgradKArgs& a, const WgradPlan& p, hipStream_t s) {
+    constexpr int MT = WM, NT = WN * NTW;
     const int PSP = a.PS + 4, XPL = (3 * PSP) | 1, DPL = (a.PS + 2) | 1;
     const size_t lds = ((size_t)NT * 32 * XPL + (size_t)MT * 32 * DPL) * sizeof(float);
-    auto kern = conv3x3_wgrad_kernel<MT, NT>;
+    auto kern = conv3x3_wgrad_kernel<WM, WN, NTW>;
     static bool attr_set = false;
     if (!attr_set) {
         int rc = scm_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -254,9 +381,9 @@ extern "C" int scm_conv3x3_wgrad(const scm_conv3x3_wgrad_desc* d, void* stream) 
     a.ci_groups = p.ci_groups;
     hipStream_t s = (hipStream_t)stream;
     int rc;
-    if (p.mt == 4) rc = launch_wgrad<4, 1>(a, p, s);
-    else if (p.mt == 2) rc = launch_wgrad<2, 2>(a, p, s);
-    else rc = launch_wgrad<1, 4>(a, p, s);
+    if (p.mt == 4) rc = launch_wgrad<4, 1, 2>(a, p, s);
+    else if (p.mt == 2) rc = launch_wgrad<2, 2, 2>(a, p, s);
+    else rc = launch_wgrad<1, 4, 1>(a, p, s);
     if (rc) return rc;
     const int total = 9 * d->cout * cin;
     const int dct = d->dw_cin_total ? d->dw_cin_total : cin;
@@ -265,7 +392,7 @@ extern "C" int scm_conv3x3_wgrad(const scm_conv3x3_wgrad_desc* d, void* stream) 
                        cin, d->transposed_dst, d->accumulate, dct, d->dw_ci0, d->dw);
     SCM_LAUNCH_CHECK("wgrad_reduce_kernel");
     if (want_cs) {
-        hipLaunchKernelGGL(csum_reduce_kernel, dim3((d->cout + 63) / 64), dim3(64), 0, s, d->csum_ws, d->B, p.spi,
+        hipLaunchKernelGGL(csum_reduce_kernel, dim3((d->cout + 63) / 64), dim3(1024), 0, s, d->csum_ws, d->B, p.spi,
                            d->cout, d->accumulate, d->csum, d->db);
         SCM_LAUNCH_CHECK("csum_reduce_kernel");
     }

@@ -99,38 +99,48 @@ __global__ void __launch_bounds__(256) smallconv_dgrad_kernel(const SmallConvArg
 }
 
 // dw[co,ci,ky,kx] = sum_{b,oy,ox} dyp[b,co,oy,ox] x[b,ci,oy*s-pad+ky,ox*s-pad+kx];  db[co] = sum dyp
+// Two deterministic phases: workgroup (co, ci, split) reduces its slice of the batch
+// into ws[split][co][ci][k] (+ ws_db[split][co]); a second kernel sums the splits.
 #define SW_MAXKK 25
 __global__ void __launch_bounds__(256) smallconv_wgrad_kernel(const SmallConvArgs a, const float* __restrict__ dy,
-                                                              float* __restrict__ dw, float* __restrict__ db,
-                                                              int accumulate) {
+                                                              float* __restrict__ ws, float* __restrict__ ws_db,
+                                                              int bps) {
     __shared__ float red[4];
-    const int co = blockIdx.x, ci = blockIdx.y;
+    const int co = blockIdx.x, ci = blockIdx.y, sp = blockIdx.z;
     const int KK = a.K * a.K;
     float acc[SW_MAXKK];
 #pragma unroll
     for (int k = 0; k < SW_MAXKK; ++k) acc[k] = 0.f;
     float bsum = 0.f;
     const int OHW = a.OH * a.OW;
-    const int total = a.B * OHW;
-    for (int e = threadIdx.x; e < total; e += 256) {
-        const int b = e / OHW;
-        const int p = e - b * OHW;
-        const int oy = p / a.OW, ox = p - oy * a.OW;
-        const size_t o = ((size_t)b * a.cout + co) * OHW + p;
-        float g = dy[o];
-        if (a.gate_act) g *= scm_act_grad_from_out(a.gate[o], a.gate_act);
-        bsum += g;
+    const int b0 = sp * bps;
+    int b1 = b0 + bps;
+    if (b1 > a.B) b1 = a.B;
+    for (int b = b0; b < b1; ++b) {
         const float* xp = a.x + ((size_t)b * a.cin + ci) * a.H * a.W;
+        const size_t ob = ((size_t)b * a.cout + co) * OHW;
+        for (int p = threadIdx.x; p < OHW; p += 256) {
+            const int oy = p / a.OW, ox = p - oy * a.OW;
+            float g = dy[ob + p];
+            if (a.gate_act) g *= scm_act_grad_from_out(a.gate[ob + p], a.gate_act);
+            bsum += g;
+            const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
 #pragma unroll
-        for (int k = 0; k < SW_MAXKK; ++k) {
-            if (k < KK) {
-                const int ky = k / a.K, kx = k - ky * a.K;
-                const int iy = oy * a.stride - a.pad + ky, ix = ox * a.stride - a.pad + kx;
-                if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) acc[k] = fmaf(g, xp[iy * a.W + ix], acc[k]);
+            for (int k = 0; k < SW_MAXKK; ++k) {
+                if (k < KK) {
+                    const int ky = k / a.K, kx = k - ky * a.K;
+                    const int iy = iy0 + ky, ix = ix0 + kx;
+                    const bool ok = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+                    const int iyc = iy < 0 ? 0 : (iy >= a.H ? a.H - 1 : iy);
+                    const int ixc = ix < 0 ? 0 : (ix >= a.W ? a.W - 1 : ix);
+                    const float xv = xp[iyc * a.W + ixc];
+                    acc[k] = fmaf(g, ok ? xv : 0.f, acc[k]);
+                }
             }
         }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* wsp = ws + (((size_t)sp * a.cout + co) * a.cin + ci) * KK;
 #pragma unroll
     for (int k = 0; k < SW_MAXKK; ++k) {
         if (k < KK) {
@@ -138,23 +148,45 @@ __global__ void __launch_bounds__(256) smallconv_wgrad_kernel(const SmallConvArg
             __syncthreads();
             if (lane == 0) red[wave] = v;
             __syncthreads();
-            if (threadIdx.x == 0) {
-                const float s = red[0] + red[1] + red[2] + red[3];
-                float* d = dw + ((size_t)co * a.cin + ci) * KK + k;
-                *d = accumulate ? *d + s : s;
-            }
+            if (threadIdx.x == 0) wsp[k] = red[0] + red[1] + red[2] + red[3];
         }
     }
-    if (db != nullptr && ci == 0) {
+    if (ws_db != nullptr && ci == 0) {
         float v = wave_sum(bsum);
         __syncthreads();
         if (lane == 0) red[wave] = v;
         __syncthreads();
-        if (threadIdx.x == 0) {
-            const float s = red[0] + red[1] + red[2] + red[3];
-            db[co] = accumulate ? db[co] + s : s;
-        }
+        if (threadIdx.x == 0) ws_db[(size_t)sp * a.cout + co] = red[0] + red[1] + red[2] + red[3];
     }
+}
+
+__global__ void smallconv_wgrad_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ ws_db,
+                                              int nsplit, int nw, int cout, int accumulate, float* __restrict__ dw,
+                                              float* __restrict__ db) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nw) {
+        float s = 0.f;
+        for (int k = 0; k < nsplit; ++k) s += ws[(size_t)k * nw + i];
+        dw[i] = accumulate ? dw[i] + s : s;
+    }
+    if (db != nullptr && i < cout) {
+        float s = 0.f;
+        for (int k = 0; k < nsplit; ++k) s += ws_db[(size_t)k * cout + i];
+        db[i] = accumulate ? db[i] + s : s;
+    }
+}
+
+static int smallconv_splits(int B, int cout, int cin) {
+    int ns = 4096 / (cout * cin);
+    if (ns < 1) ns = 1;
+    if (ns > B) ns = B;
+    return ns;
+}
+
+extern "C" size_t scm_conv2d_bwd_workspace(int B, int cin, int cout, int K) {
+    if (B <= 0 || cin <= 0 || cout <= 0 || K <= 0) return 0;
+    const int ns = smallconv_splits(B, cout, cin);
+    return (size_t)ns * ((size_t)cout * cin * K * K + cout);
 }
 
 static int fill_args(const scm_conv2d_desc* d, SmallConvArgs* a, const char* who) {
@@ -183,7 +215,7 @@ extern "C" int scm_conv2d_fwd(const scm_conv2d_desc* d, void* stream) {
 }
 
 extern "C" int scm_conv2d_bwd(const scm_conv2d_desc* d, const float* dy, float* dx, float* dw, float* db,
-                              int accumulate, void* stream) {
+                              int accumulate, float* ws, void* stream) {
     SmallConvArgs a;
     int rc = fill_args(d, &a, "scm_conv2d_bwd");
     if (rc) return rc;
@@ -195,10 +227,18 @@ extern "C" int scm_conv2d_bwd(const scm_conv2d_desc* d, const float* dy, float* 
         SCM_LAUNCH_CHECK("smallconv_dgrad_kernel");
     }
     if (dw) {
-        SCM_REQUIRE(d->x, "scm_conv2d_bwd: x required for dw");
-        dim3 grid(a.cout, a.cin);
-        hipLaunchKernelGGL(smallconv_wgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, a, dy, dw, db, accumulate);
+        SCM_REQUIRE(d->x && ws, "scm_conv2d_bwd: x and the workspace are required for dw");
+        const int ns = smallconv_splits(a.B, a.cout, a.cin);
+        const int bps = (a.B + ns - 1) / ns;
+        const int nw = a.cout * a.cin * a.K * a.K;
+        float* ws_db = ws + (size_t)ns * nw;
+        dim3 grid(a.cout, a.cin, ns);
+        hipLaunchKernelGGL(smallconv_wgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, a, dy, ws,
+                           db ? ws_db : nullptr, bps);
         SCM_LAUNCH_CHECK("smallconv_wgrad_kernel");
+        hipLaunchKernelGGL(smallconv_wgrad_reduce_kernel, dim3((nw + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws,
+                           ws_db, ns, nw, a.cout, accumulate, dw, db);
+        SCM_LAUNCH_CHECK("smallconv_wgrad_reduce_kernel");
     }
     return SCM_OK;
 }

@@ -71,6 +71,13 @@ class Conv2d(nn.Module):
             return ops.Conv3x3Fn.apply(x, x2, act_vec, w, self.bias, inv_sigma, u, v, cfg)
         if x2 is not None or act_vec is not None:
             raise ValueError("two-input / action-plane forms need the 3x3 same-size geometry")
+        if self.kernel_size == 3 and self.stride == 1 and self.padding == 0 and x.shape[2] > 2 and x.shape[3] > 2:
+            # "valid" 3x3 (RewardPredictor.conv1, models.py:230): the interior of the zero-padded
+            # same-size conv, so it runs on the MFMA kernels; the border ring is cropped away
+            # (the crop and its zero-embedding backward are plain copies).
+            cfg = {"pad": ops.PAD_ZERO, "act": act, "transposed": False, "packs": self._get_packs(w, x.shape[1])}
+            full = ops.Conv3x3Fn.apply(x, None, None, w, self.bias, inv_sigma, u, v, cfg)
+            return full[:, :, 1:-1, 1:-1].contiguous()
         return ops.Conv2dFn.apply(x, w, self.bias, inv_sigma, u, v, self.kernel_size, self.stride, self.padding, act)
 
     def extra_repr(self):

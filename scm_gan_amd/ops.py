@@ -87,7 +87,7 @@ kernel_timer = None     # set to a KernelTimer() to time the MFMA conv launches
 
 
 def conv_kernel_name(cout):
-    return "conv3x3_mfma_kernel<%s>" % ("4,2" if cout > 64 else ("2,4" if cout > 32 else "1,4"))
+    return "conv3x3_mfma_kernel<%s>" % ("4,4" if cout > 64 else ("2,4" if cout > 32 else "1,8"))
 
 
 def _conv3x3_raw(x1, x2, gate1, gate2, gate_act, wpack, cout, scale, bias, sbias, co1, pad, act):
@@ -239,7 +239,9 @@ class Conv2dFn(Function):
         db = _new(gy, cout) if (need_w or need_b) else None
         d = L.Conv2dDesc(_p(x), _p(w), None, _p(inv_sigma), None, _p(y) if act else None, act, B, cin, H, W, cout, K,
                          stride, pad, act)
-        L.check(lib.scm_conv2d_bwd(ctypes.byref(d), _p(gy), _p(dx), _p(dw_eff), _p(db), 0, _stream()), "scm_conv2d_bwd")
+        ws = _new(gy, lib.scm_conv2d_bwd_workspace(B, cin, cout, K)) if dw_eff is not None else None
+        L.check(lib.scm_conv2d_bwd(ctypes.byref(d), _p(gy), _p(dx), _p(dw_eff), _p(db), 0, _p(ws), _stream()),
+                "scm_conv2d_bwd")
         dw = dw_eff
         if dw_eff is not None and inv_sigma is not None:
             dw = _sn_fold(dw_eff, w, u, v, inv_sigma)

@@ -16,7 +16,7 @@ def pack(w, transposed=False):
     nf = lib.scm_conv3x3_pack_floats(cin, cout)
     nd = lib.scm_conv3x3_pack_floats(cout, cin)
     fp = torch.empty(nf, device=dev); dp = torch.empty(nd, device=dev)
-    L.check(lib.scm_pack_conv3x3_weights(L.ptr(w), cin, cout, int(transposed), L.ptr(fp), L.ptr(dp), L.stream_ptr()), 'pack')
+    L.check(lib.scm_pack_conv3x3_weights(L.ptr(w), cin, cout, int(transposed), 0, 0, L.ptr(fp), L.ptr(dp), L.stream_ptr()), "pack")
     return fp, dp
 
 def conv(x1, x2, wp, cout, pad, act, bias=None, sbias=None, scale=None, gate1=None, gate2=None, gate_act=0, co1=None):
@@ -90,7 +90,7 @@ def wgrad(x1, x2, dy, gate, gate_act, pad, transposed=False):
     dw = torch.empty((cin, cout, 3, 3) if transposed else (cout, cin, 3, 3), device=dev)
     db = torch.empty(cout, device=dev); csum = torch.empty(B, cout, device=dev)
     d = L.WgradDesc(L.ptr(x1), L.ptr(x2), c1, c2, L.ptr(dy), L.ptr(gate), gate_act, cout, L.ptr(dw), L.ptr(db), L.ptr(csum),
-                    L.ptr(part), L.ptr(cs), B, H, W, pad, int(transposed), 0)
+                    L.ptr(part), L.ptr(cs), B, H, W, pad, int(transposed), 0, 0, 0)
     L.check(lib.scm_conv3x3_wgrad(ctypes.byref(d), L.stream_ptr()), 'wgrad')
     return dw, db, csum
 
