@@ -120,6 +120,8 @@ typedef struct scm_conv3x3_wgrad_desc {
     int32_t B; int32_t H; int32_t W; int32_t pad_mode;
     int32_t transposed_dst; int32_t accumulate;
     int32_t dw_cin_total; int32_t dw_ci0;   /* dw holds dw_cin_total input channels (0 = c1+c2); write slice at dw_ci0 */
+    const float* dot_w; float* dot_part;    /* optional: dot_part[i] = partial <dw, dot_w> of reduce block i
+                                               (ceil(9*cout*cin/256) floats) for scm_sn_fold_grad */
 } scm_conv3x3_wgrad_desc;
 
 int scm_conv3x3_wgrad_workspace(int B, int H, int W, int cin, int cout, size_t* part_floats,
@@ -149,7 +151,10 @@ typedef struct scm_sn_layer {
 
 int scm_sn_power_iter(int nlayers, const scm_sn_layer* layers, int steps, void* stream);
 int scm_sn_fold_grad(const float* g, const float* w_bar, const float* u, const float* v, const float* inv_sigma,
-                     int rows, int cols, int accumulate, float* dw_bar, void* stream);
+                     const float* dot_part, int ndot, int rows, int cols, int accumulate, float* dw_bar,
+                     void* stream);
+/* dot_part/ndot: optional partial sums of <g, W_bar> (from scm_conv3x3_wgrad); when NULL the
+ * dot product is computed here by one workgroup. */
 
 /* ------------------------------------------------------------------------
  * Generic small Conv2d (square kernel K, stride, zero padding `pad`), direct

@@ -41,6 +41,7 @@ class WgradDesc(ctypes.Structure):
         ("B", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32), ("pad_mode", ctypes.c_int32),
         ("transposed_dst", ctypes.c_int32), ("accumulate", ctypes.c_int32),
         ("dw_cin_total", ctypes.c_int32), ("dw_ci0", ctypes.c_int32),
+        ("dot_w", ctypes.c_void_p), ("dot_part", ctypes.c_void_p),
     ]
 
 
@@ -84,7 +85,7 @@ def lib():
             "scm_conv3x3_wgrad_workspace": [ci, ci, ci, ci, ci, vp, vp],
             "scm_conv3x3_wgrad": [vp, vp],
             "scm_sn_power_iter": [ci, vp, ci, vp],
-            "scm_sn_fold_grad": [vp, vp, vp, vp, vp, ci, ci, ci, vp, vp],
+            "scm_sn_fold_grad": [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp, vp],
             "scm_conv2d_fwd": [vp, vp],
             "scm_conv2d_bwd": [vp, vp, vp, vp, vp, ci, vp, vp],
             "scm_conv2d_bwd_workspace": [ci, ci, ci, ci],

@@ -253,11 +253,16 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wgrad_kernel(const WgradKArgs 
 // Sum the per-split slabs in split order and scatter into the torch layout.
 //   dw[co][ci][3][3]                    (transposed_dst == 0, nn.Conv2d)
 //   dw[ci][co][3][3] with taps flipped  (transposed_dst == 1, nn.ConvTranspose2d)
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, int cout, int cin,
-                                    int transposed_dst, int accumulate, int dct, int dc0, float* __restrict__ dw) {
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, int cout,
+                                                           int cin, int transposed_dst, int accumulate, int dct,
+                                                           int dc0, float* __restrict__ dw,
+                                                           const float* __restrict__ dot_w,
+                                                           float* __restrict__ dot_part) {
+    __shared__ float red[4];
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int per_tap = cout * cin;
-    if (idx >= 9 * per_tap) return;
+    float prod = 0.f;
+    if (idx < 9 * per_tap) {
     const int t = idx / per_tap;
     const int rem = idx - t * per_tap;
     const int co = rem / cin, ci = rem - co * cin;
@@ -274,6 +279,14 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, 
     const size_t o = transposed_dst ? ((size_t)(dc0 + ci) * cout + co) * 9 + (8 - t)
                                     : ((size_t)co * dct + dc0 + ci) * 9 + t;
     dw[o] = accumulate ? dw[o] + s : s;
+    if (dot_w) prod = s * dot_w[o];
+    }
+    if (dot_part) {      // <dW_eff, W_bar> partial of this block, for the SpectralNorm fold
+        prod = wave_sum(prod);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = prod;
+        __syncthreads();
+        if (threadIdx.x == 0) dot_part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    }
 }
 
 // csum[b][co] = sum over the image's splits; db[co] = sum_b csum[b][co].
@@ -388,8 +401,9 @@ extern "C" int scm_conv3x3_wgrad(const scm_conv3x3_wgrad_desc* d, void* stream) 
     const int total = 9 * d->cout * cin;
     const int dct = d->dw_cin_total ? d->dw_cin_total : cin;
     SCM_REQUIRE(d->dw_ci0 >= 0 && d->dw_ci0 + cin <= dct, "scm_conv3x3_wgrad: bad dw channel slice");
+    SCM_REQUIRE(!d->dot_w || (d->dot_part && !d->accumulate), "scm_conv3x3_wgrad: dot_w needs dot_part and accumulate == 0");
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, d->part_ws, p.nsplit, d->cout,
-                       cin, d->transposed_dst, d->accumulate, dct, d->dw_ci0, d->dw);
+                       cin, d->transposed_dst, d->accumulate, dct, d->dw_ci0, d->dw, d->dot_w, d->dot_w ? d->dot_part : nullptr);
     SCM_LAUNCH_CHECK("wgrad_reduce_kernel");
     if (want_cs) {
         hipLaunchKernelGGL(csum_reduce_kernel, dim3((d->cout + 63) / 64), dim3(1024), 0, s, d->csum_ws, d->B, p.spi,

@@ -136,10 +136,43 @@ __global__ void __launch_bounds__(SN_THREADS) sn_fold_kernel(const float* __rest
     }
 }
 
+// Same fold with <g, W_bar> given as ndot partial sums (wgrad_reduce_kernel): every
+// workgroup re-reduces the (<= few thousand) partials in the same fixed order, then
+// handles its slice of the matrix -- no single-workgroup pass over the weights.
+__global__ void __launch_bounds__(256) sn_fold_parts_kernel(const float* __restrict__ g,
+                                                            const float* __restrict__ u, const float* __restrict__ v,
+                                                            const float* __restrict__ inv_sigma,
+                                                            const float* __restrict__ dot_part, int ndot, int rows,
+                                                            int cols, int accumulate, float* __restrict__ dwbar) {
+    __shared__ float red[4];
+    float part = 0.f;
+    for (int i = threadIdx.x; i < ndot; i += 256) part += dot_part[i];
+    part = wave_sum(part);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+    __syncthreads();
+    const float dot = (red[0] + red[1]) + (red[2] + red[3]);
+    const float is = *inv_sigma;
+    const float c = dot * is * is;
+    const int n = rows * cols;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int r = i / cols, j = i - r * cols;
+        const float val = g[i] * is - c * u[r] * v[j];
+        dwbar[i] = accumulate ? dwbar[i] + val : val;
+    }
+}
+
 extern "C" int scm_sn_fold_grad(const float* g, const float* w_bar, const float* u, const float* v,
-                                const float* inv_sigma, int rows, int cols, int accumulate, float* dw_bar,
-                                void* stream) {
+                                const float* inv_sigma, const float* dot_part, int ndot, int rows, int cols,
+                                int accumulate, float* dw_bar, void* stream) {
     SCM_REQUIRE(g && w_bar && u && v && inv_sigma && dw_bar && rows > 0 && cols > 0, "scm_sn_fold_grad: bad arguments");
+    if (dot_part != nullptr && ndot > 0) {
+        int blocks = (rows * cols + 256 * 4 - 1) / (256 * 4);
+        if (blocks > 512) blocks = 512;
+        hipLaunchKernelGGL(sn_fold_parts_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, u, v, inv_sigma,
+                           dot_part, ndot, rows, cols, accumulate, dw_bar);
+        SCM_LAUNCH_CHECK("sn_fold_parts_kernel");
+        return SCM_OK;
+    }
     hipLaunchKernelGGL(sn_fold_kernel, dim3(1), dim3(SN_THREADS), 0, (hipStream_t)stream, g, w_bar, u, v, inv_sigma,
                        rows, cols, accumulate, dw_bar);
     SCM_LAUNCH_CHECK("sn_fold_kernel");

@@ -25,6 +25,7 @@ from . import ops
 from .datasource import allocate_datasource
 from .logutil import TimeSeries, sparkline
 from .optim import AdamClip
+from . import spectral_normalization as SN
 
 parser = argparse.ArgumentParser(description="Learn to model a sequential environment")
 parser.add_argument('--env', default='synthetic_minipacman', help='Datasource name (see scm_gan_amd/datasource.py)')
@@ -169,6 +170,7 @@ class Trainer(object):
         for o in (self.opt_enc, self.opt_dec, self.opt_trans, self.opt_pred):
             o.grad_scale = 1.0 / self.world
         self.ts = TimeSeries('Training Model', self.a.train_iters, tensorboard=True)
+        self.side_stream = torch.cuda.Stream()
 
     def step(self, states, rewards, dones, onehots, theta, train_iter=1, actions=None):
         """states (B,T,C,H,W), rewards (B,T,R), dones (B,T) as 0/1 floats, onehots
@@ -187,7 +189,17 @@ class Trainer(object):
         for f in self.flats:
             f.zero()
 
+        # SpectralNorm power iterations depend on the weights only: the encoder's three
+        # run in one launch, and the (horizon-2) x 5 of the unrolled transition run
+        # on a side stream underneath the encoder's convolutions.
+        SN.precompute([encoder], 1)
+        main_stream = torch.cuda.current_stream()
+        self.side_stream.wait_stream(main_stream)
+        with torch.cuda.stream(self.side_stream):
+            SN.precompute([transition], prediction_horizon - 2)
+
         z = encoder(states[:, 0:3])                                            # main.py:162
+        main_stream.wait_stream(self.side_stream)
         z_orig = z.clone() if (enable_cf_shuffle_loss or enable_control_bias_loss) else None
         active_mask = torch.ones(batch_size, device=states.device)
 

@@ -121,13 +121,31 @@ def sn_power_iter(weight_bar, u, v):
     return sigma, inv_sigma
 
 
-def _sn_fold(g, weight_bar, u, v, inv_sigma):
+def sn_power_iter_multi(layers, steps):
+    """`steps` consecutive power iterations for up to 8 (weight_bar, u, v) triples in
+    ONE launch (one workgroup per layer).  Returns a (nlayers, 2, steps) tensor:
+    [:, 0] = sigma after each call, [:, 1] = 1/sigma."""
+    lib = L.lib()
+    n = len(layers)
+    w0 = layers[0][0]
+    out = _new(w0, n, 2, steps)
+    arr = (L.SnLayer * n)()
+    for i, (w, u, v) in enumerate(layers):
+        w = _chk(w.detach(), "sn_power_iter_multi")
+        rows = w.shape[0]
+        arr[i] = L.SnLayer(_p(w), _p(u.data), _p(v.data), _p(out[i, 0]), _p(out[i, 1]), rows, w.numel() // rows)
+    L.check(lib.scm_sn_power_iter(n, arr, steps, _stream()), "scm_sn_power_iter")
+    return out
+
+
+def _sn_fold(g, weight_bar, u, v, inv_sigma, dot_part=None):
     lib = L.lib()
     rows = weight_bar.shape[0]
     cols = weight_bar.numel() // rows
     out = torch.empty_like(g)
-    L.check(lib.scm_sn_fold_grad(_p(g), _p(weight_bar), _p(u), _p(v), _p(inv_sigma), rows, cols, 0, _p(out), _stream()),
-            "scm_sn_fold_grad")
+    ndot = 0 if dot_part is None else dot_part.numel()
+    L.check(lib.scm_sn_fold_grad(_p(g), _p(weight_bar), _p(u), _p(v), _p(inv_sigma), _p(dot_part), ndot, rows, cols, 0,
+                                 _p(out), _stream()), "scm_sn_fold_grad")
     return out
 
 
@@ -191,9 +209,14 @@ class Conv3x3Fn(Function):
             dw_eff = torch.empty_like(w)
             db = _new(gy, cout)
             csum = _new(gy, B, cout) if has_act else None
+            # <dW_eff, W_bar> partials for the SpectralNorm fold come out of the reduce kernel
+            # (not when action channels add their slice afterwards: the fold then does the dot itself)
+            dot_part = None
+            if inv_sigma is not None and not has_act:
+                dot_part = _new(gy, (9 * cout * (c1 + c2) + 255) // 256)
             d = L.WgradDesc(_p(x1), _p(x2), c1, c2, _p(gy), _p(y) if act else None, act, cout, _p(dw_eff), _p(db),
                             _p(csum), _p(part), _p(cws), B, H, W, cfg["pad"], int(cfg["transposed"]), 0,
-                            cin_total, 0)
+                            cin_total, 0, _p(w) if dot_part is not None else None, _p(dot_part))
             L.check(lib.scm_conv3x3_wgrad(ctypes.byref(d), _stream()), "scm_conv3x3_wgrad")
             if has_act:
                 A = act_vec.shape[1]
@@ -201,7 +224,7 @@ class Conv3x3Fn(Function):
                 L.check(lib.scm_action_bias_bwd(_p(act_vec), _p(w), _p(inv_sigma), _p(csum), B, A, cout, cin_total,
                                                 c1 + c2, _p(d_act), _p(dw_eff), _stream()), "scm_action_bias_bwd")
             if inv_sigma is not None:
-                dw = _sn_fold(dw_eff, w, u, v, inv_sigma)
+                dw = _sn_fold(dw_eff, w, u, v, inv_sigma, dot_part)
             else:
                 dw = dw_eff
         return (dx1 if need_x1 else None, dx2 if need_x2 else None, d_act if need_a else None,

@@ -25,6 +25,7 @@ class SpectralNorm(nn.Module):
         self.module = module
         self.name = name
         self.power_iterations = power_iterations
+        self._precomputed = []      # (sigma, inv_sigma) of power iterations already run (see precompute())
         if not self._made_params():
             self._make_params()
 
@@ -58,6 +59,9 @@ class SpectralNorm(nn.Module):
         v = getattr(self.module, self.name + "_v")
         w = getattr(self.module, self.name + "_bar")
         sigma = inv_sigma = None
+        if self._precomputed:
+            sigma, inv_sigma = self._precomputed.pop(0)
+            return w, u, v, sigma, inv_sigma
         for _ in range(self.power_iterations):
             sigma, inv_sigma = ops.sn_power_iter(w, u, v)
         return w, u, v, sigma, inv_sigma
@@ -69,3 +73,24 @@ class SpectralNorm(nn.Module):
             raise TypeError("scm_gan_amd.SpectralNorm wraps scm_gan_amd.layers modules (Conv2d); got %r"
                             % type(self.module).__name__)
         return self.module.forward(*args, _sn=(w, u, v, inv_sigma), **kwargs)
+
+
+def precompute(modules, calls):
+    """Run the power iterations of the next `calls` forward calls of every
+    SpectralNorm found in `modules`, batched: the iteration depends only on
+    (W_bar, u, v), never on the data, so all of an unrolled rollout's iterations
+    can run ahead of it in one launch per 8 layers (u, v end in the same state and
+    every call still sees its own sigma).  Results are queued per module and
+    consumed by the following forward calls; valid only while W_bar is unchanged."""
+    sns = []
+    for m in modules:
+        sns += [x for x in m.modules() if isinstance(x, SpectralNorm) and x.power_iterations == 1
+                and x.name == 'weight']
+    for i in range(0, len(sns), 8):
+        group = sns[i:i + 8]
+        layers = [(getattr(x.module, "weight_bar"), getattr(x.module, "weight_u"), getattr(x.module, "weight_v"))
+                  for x in group]
+        out = ops.sn_power_iter_multi(layers, calls)
+        for k, x in enumerate(group):
+            x._precomputed += [(out[k, 0, c:c + 1], out[k, 1, c:c + 1]) for c in range(calls)]
+    return len(sns)

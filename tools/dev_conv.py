@@ -90,7 +90,7 @@ def wgrad(x1, x2, dy, gate, gate_act, pad, transposed=False):
     dw = torch.empty((cin, cout, 3, 3) if transposed else (cout, cin, 3, 3), device=dev)
     db = torch.empty(cout, device=dev); csum = torch.empty(B, cout, device=dev)
     d = L.WgradDesc(L.ptr(x1), L.ptr(x2), c1, c2, L.ptr(dy), L.ptr(gate), gate_act, cout, L.ptr(dw), L.ptr(db), L.ptr(csum),
-                    L.ptr(part), L.ptr(cs), B, H, W, pad, int(transposed), 0, 0, 0)
+                    L.ptr(part), L.ptr(cs), B, H, W, pad, int(transposed), 0, 0, 0, None, None)
     L.check(lib.scm_conv3x3_wgrad(ctypes.byref(d), L.stream_ptr()), 'wgrad')
     return dw, db, csum
 
