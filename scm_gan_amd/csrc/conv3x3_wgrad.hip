@@ -18,6 +18,7 @@
 // order (bitwise reproducible, no float atomics).  Per-sample channel sums of
 // dyp (bias gradient, action-plane gradients) fall out of the A operands.
 #include "common.h"
+#include <type_traits>
 
 struct WgradKArgs {
     const float* x1; const float* x2; int c1; int c2;
@@ -28,18 +29,19 @@ struct WgradKArgs {
     int ci_groups;
 };
 
-// 4 waves as WM x WN, one wave per SIMD with the whole 512-register budget: wave
-// (wm, wn) owns co tile wm and NTW ci tiles, i.e. 9*NTW accumulator tiles (288
-// VGPRs at NTW = 2) plus the prefetch registers.  Software pipeline per image
-// row y of the band:
+// WM x WN waves (8 = two per SIMD for the big layers); wave (wm, wn) owns co tile
+// wm and NTW ci tiles, i.e. 9*NTW accumulator tiles of 16 registers.  NTW = 1 keeps
+// the 144 accumulators inside the AGPR half of the register file: at NTW = 2 (288)
+// hipcc shuttles tiles between AGPRs and VGPRs inside the k loop.  Software
+// pipeline per image row y of the band:
 //   barrier | registers -> LDS (x row y+1 into the rolling slot, dyp row y) |
 //   barrier | issue global loads of row y+1's data into registers | 288 MFMAs
 // so the HBM/L2 latency of the next row hides under this row's MFMAs.
 template <int WM, int WN, int NTW>
-__global__ void __launch_bounds__(256, 1) conv3x3_wgrad_kernel(const WgradKArgs a) {
+__global__ void __launch_bounds__(WM * WN * 64, (WM * WN) / 4) conv3x3_wgrad_kernel(const WgradKArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    static_assert(WM * WN == 4, "4 waves");
-    constexpr int NW = 4;
+    static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves");
+    constexpr int NW = WM * WN;
     constexpr int MT = WM;                 // co tiles per workgroup
     constexpr int NT = WN * NTW;           // ci tiles per workgroup
     constexpr int DR = MT * 32 / NW;       // dy rows staged per wave
@@ -82,6 +84,13 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wgrad_kernel(const WgradKArgs 
 
     const float* ap = dyl + (wm * 32 + l31) * DPL + lh;
     const float* bp = xl + (wn * NTW * 32 + l31) * XPL + lh;
+    bool tile_live[NTW];
+#pragma unroll
+    for (int n = 0; n < NTW; ++n)
+        tile_live[n] = (ci_base + (wn * NTW + n) * 32 < cin) && (co_base + wm * 32 < a.cout);
+    bool all_live = true;
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) all_live = all_live && tile_live[n];
 
     // Every global load below is UNCONDITIONAL on a clamped, always-valid address and
     // masked afterwards with a select: a load under a per-lane condition makes hipcc
@@ -207,25 +216,33 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wgrad_kernel(const WgradKArgs 
                     bv[n][6] = q[ro2]; bv[n][7] = q[ro2 + 1]; bv[n][8] = q[ro2 + 2];
                 }
             };
-            auto mfma_k = [&](float av, const float (&bv)[NTW][9]) {
+            auto mfma_k = [&](float av, const float (&bv)[NTW][9], auto checked) {
                 if (do_csum) csum += av;
 #pragma unroll
-                for (int n = 0; n < NTW; ++n)
+                for (int n = 0; n < NTW; ++n) {
+                    // wave-uniform: ci tiles beyond cin (co tiles beyond cout) do no MFMA work
+                    if (!decltype(checked)::value || tile_live[n]) {
 #pragma unroll
-                    for (int t = 0; t < 9; ++t)
-                        acc[n][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[n][t], acc[n][t], 0, 0, 0);
+                        for (int t = 0; t < 9; ++t)
+                            acc[n][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[n][t], acc[n][t], 0, 0, 0);
+                    }
+                }
             };
-            float av0, av1, bv0[NTW][9], bv1[NTW][9];
-            lds_k(0, av0, bv0);
+            auto row_loop = [&](auto checked) {
+                float av0, av1, bv0[NTW][9], bv1[NTW][9];
+                lds_k(0, av0, bv0);
 #pragma unroll 1
-            for (int ks = 0; ks < nks; ks += 2) {
-                const int k1 = ks + 1 < nks ? ks + 1 : nks - 1;
-                lds_k(k1, av1, bv1);
-                mfma_k(av0, bv0);
-                const int k2 = ks + 2 < nks ? ks + 2 : nks - 1;
-                lds_k(k2, av0, bv0);
-                if (ks + 1 < nks) mfma_k(av1, bv1);
-            }
+                for (int ks = 0; ks < nks; ks += 2) {
+                    const int k1 = ks + 1 < nks ? ks + 1 : nks - 1;
+                    lds_k(k1, av1, bv1);
+                    mfma_k(av0, bv0, checked);
+                    const int k2 = ks + 2 < nks ? ks + 2 : nks - 1;
+                    lds_k(k2, av0, bv0);
+                    if (ks + 1 < nks) mfma_k(av1, bv1, checked);
+                }
+            };
+            if (all_live) row_loop(std::false_type{});
+            else row_loop(std::true_type{});
         }
     }
 
@@ -323,9 +340,9 @@ struct WgradPlan {
 
 static int wgrad_plan(int B, int H, int W, int cin, int cout, WgradPlan* p) {
     const int cot = (cout + 31) / 32, cit = (cin + 31) / 32;
-    if (cot >= 3) { p->mt = 4; p->nt = 2; }          // 128 co x 64 ci per workgroup
-    else if (cot == 2) { p->mt = 2; p->nt = 4; }     //  64 co x 128 ci
-    else { p->mt = 1; p->nt = 4; }                   //  32 co x 128 ci
+    if (cot >= 3) { p->mt = 4; p->nt = cit >= 2 ? 2 : 1; }     // 128 co x 64 (32) ci per workgroup
+    else if (cot == 2) { p->mt = 2; p->nt = cit >= 3 ? 4 : 2; } //  64 co x 128 (64) ci
+    else { p->mt = 1; p->nt = 4; }                             //  32 co x 128 ci
     p->co_groups = (cot + p->mt - 1) / p->mt;
     p->ci_groups = (cit + p->nt - 1) / p->nt;
     p->nseg = (W + 63) / 64;
@@ -366,7 +383,7 @@ static int launch_wgrad(const WgradKArgs& a, const WgradPlan& p, hipStream_t s) 
         attr_set = true;
     }
     dim3 grid(p.nsplit, p.co_groups * p.ci_groups);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, s, a);
     SCM_LAUNCH_CHECK("conv3x3_wgrad_kernel");
     return SCM_OK;
 }
@@ -394,8 +411,8 @@ extern "C" int scm_conv3x3_wgrad(const scm_conv3x3_wgrad_desc* d, void* stream) 
     a.ci_groups = p.ci_groups;
     hipStream_t s = (hipStream_t)stream;
     int rc;
-    if (p.mt == 4) rc = launch_wgrad<4, 1, 2>(a, p, s);
-    else if (p.mt == 2) rc = launch_wgrad<2, 2, 2>(a, p, s);
+    if (p.mt == 4) rc = p.nt == 2 ? launch_wgrad<4, 2, 1>(a, p, s) : launch_wgrad<4, 1, 1>(a, p, s);
+    else if (p.mt == 2) rc = p.nt == 4 ? launch_wgrad<2, 4, 1>(a, p, s) : launch_wgrad<2, 2, 1>(a, p, s);
     else rc = launch_wgrad<1, 4, 1>(a, p, s);
     if (rc) return rc;
     const int total = 9 * d->cout * cin;
