@@ -235,6 +235,27 @@ int scm_adam_clip_multi(int count, float* const* params, float* const* grads, fl
                         float* const* exp_avg_sq, const int* numel, float lr, float beta1, float beta2, float eps,
                         int step, float clip_value, float grad_scale, void* stream);
 
+/* ------------------------------------------------------------------------
+ * CSRN directional sweep (spatial_recurrent.py:55-114): per image row (along_rows
+ * = 1; per column otherwise), in sweep order (reverse = 1: from the last), a
+ * one-step bias-free GRU over the row's tokens -> ctx row; Conv1d(k=3, pad 1) +
+ * tanh of that output is the hidden state of the next row.
+ *   fwd: writes ctx[B][ch][H][W] and hprev[steps][B][ntok][ch] (state entering
+ *        each step, kept for the backward pass).
+ *   bwd: BPTT. dx is ACCUMULATED into (caller zero-fills; the sweeps of one CSRN
+ *        add up); dparams[9*ch*ch + ch] = [d w_ih (3ch x ch), d w_hh (3ch x ch),
+ *        d wc (ch x ch x 3), d bc (ch)]; slab = workspace of B * (9*ch*ch + ch).
+ * ---------------------------------------------------------------------- */
+typedef struct scm_csrn_desc {
+    const float* x; float* ctx; float* hprev;
+    const float* w_ih; const float* w_hh; const float* wc; const float* bc;
+    int32_t B; int32_t ch; int32_t H; int32_t W; int32_t along_rows; int32_t reverse;
+} scm_csrn_desc;
+
+int scm_csrn_sweep_fwd(const scm_csrn_desc* d, void* stream);
+int scm_csrn_sweep_bwd(const scm_csrn_desc* d, const float* dctx, float* dx, float* slab, float* dparams,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

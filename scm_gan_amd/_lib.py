@@ -61,6 +61,14 @@ class Conv2dDesc(ctypes.Structure):
                 ("act", ctypes.c_int32)]
 
 
+class CsrnDesc(ctypes.Structure):
+    """Mirror of scm_csrn_desc."""
+    _fields_ = [("x", ctypes.c_void_p), ("ctx", ctypes.c_void_p), ("hprev", ctypes.c_void_p),
+                ("w_ih", ctypes.c_void_p), ("w_hh", ctypes.c_void_p), ("wc", ctypes.c_void_p), ("bc", ctypes.c_void_p),
+                ("B", ctypes.c_int32), ("ch", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32),
+                ("along_rows", ctypes.c_int32), ("reverse", ctypes.c_int32)]
+
+
 _lib = None
 
 
@@ -101,6 +109,8 @@ def lib():
             "scm_linear": [vp, vp, vp, ci, ci, ci, ci, vp, vp],
             "scm_linear_bwd": [vp, vp, vp, vp, ci, ci, ci, ci, vp, vp, vp, vp],
             "scm_coord_cat": [vp, vp, ci, ci, ci, ci, vp],
+            "scm_csrn_sweep_fwd": [vp, vp],
+            "scm_csrn_sweep_bwd": [vp, vp, vp, vp, vp, vp],
             "scm_adam_clip_multi": [ci, vp, vp, vp, vp, vp, cf, cf, cf, cf, ci, cf, cf, vp],
         }
         for name, args in sigs.items():

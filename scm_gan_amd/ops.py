@@ -423,3 +423,66 @@ def pixel_mse(logit, target):
 
 def pixel_bce(logit, target):
     return PixelLossFn.apply(logit, target, 0)
+
+
+class CSRNSweepsFn(Function):
+    """The directional sweeps of CSRN.forward (spatial_recurrent.py:55-116) -> the
+    concatenated context map (B, 4*ch, H, W) = [above | below | left | right].
+
+    Reference behaviour kept: the right sweep writes context_left (:110), which
+    overwrites the left sweep, and context_right stays zero -- so the left sweep
+    is not computed and its parameters get zero gradients.
+    params: 4 tensors (w_ih, w_hh, conv weight, conv bias) for each of
+    down, up, left, right, in that order."""
+
+    SWEEPS = (("down", 1, 0, 0), ("up", 1, 1, 1), ("right", 0, 1, 2))   # name, along_rows, reverse, context slot
+
+    @staticmethod
+    def forward(ctx, x, *params):
+        lib = L.lib()
+        x = _chk(x, "csrn")
+        params = [_chk(p.detach(), "csrn") for p in params]
+        B, ch, H, W = x.shape
+        cmap = torch.zeros(B, 4 * ch, H, W, device=x.device, dtype=torch.float32)
+        saved = []
+        by_name = {"down": params[0:4], "up": params[4:8], "left": params[8:12], "right": params[12:16]}
+        for name, along, rev, slot in CSRNSweepsFn.SWEEPS:
+            w_ih, w_hh, wc, bc = by_name[name]
+            ntok, nsteps = (W, H) if along else (H, W)
+            cbuf = _new(x, B, ch, H, W)
+            hprev = _new(x, nsteps, B, ntok, ch)
+            d = L.CsrnDesc(_p(x), _p(cbuf), _p(hprev), _p(w_ih), _p(w_hh), _p(wc), _p(bc), B, ch, H, W, along, rev)
+            L.check(lib.scm_csrn_sweep_fwd(ctypes.byref(d), _stream()), "scm_csrn_sweep_fwd")
+            cmap[:, slot * ch:(slot + 1) * ch] = cbuf
+            saved += [cbuf, hprev]
+        ctx.geom = (B, ch, H, W)
+        ctx.save_for_backward(x, *params, *saved)
+        return cmap
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = L.lib()
+        B, ch, H, W = ctx.geom
+        t = ctx.saved_tensors
+        x, params, saved = t[0], t[1:17], t[17:]
+        g = _chk(g, "csrn.backward")
+        by_name = {"down": params[0:4], "up": params[4:8], "left": params[8:12], "right": params[12:16]}
+        dx = torch.zeros_like(x)
+        nparam = 9 * ch * ch + ch
+        grads = {"left": [torch.zeros_like(p) for p in by_name["left"]]}
+        for i, (name, along, rev, slot) in enumerate(CSRNSweepsFn.SWEEPS):
+            w_ih, w_hh, wc, bc = by_name[name]
+            cbuf, hprev = saved[2 * i], saved[2 * i + 1]
+            dctx = g[:, slot * ch:(slot + 1) * ch].contiguous()
+            slab = _new(x, B, nparam)
+            dpar = _new(x, nparam)
+            d = L.CsrnDesc(_p(x), _p(cbuf), _p(hprev), _p(w_ih), _p(w_hh), _p(wc), _p(bc), B, ch, H, W, along, rev)
+            L.check(lib.scm_csrn_sweep_bwd(ctypes.byref(d), _p(dctx), _p(dx), _p(slab), _p(dpar), _stream()),
+                    "scm_csrn_sweep_bwd")
+            n3 = 3 * ch * ch
+            grads[name] = [dpar[0:n3].view(3 * ch, ch), dpar[n3:2 * n3].view(3 * ch, ch),
+                           dpar[2 * n3:3 * n3].view(ch, ch, 3), dpar[3 * n3:]]
+        out = [dx]
+        for name in ("down", "up", "left", "right"):
+            out += grads[name]
+        return tuple(out)

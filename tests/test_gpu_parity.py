@@ -154,6 +154,26 @@ def test_operators_vs_golden(M):
     check(fx, "cc_grad_x", xc.grad, ATOL)
     check(fx, "cc_grad.conv.weight", cc.conv.weight.grad, 5e-4, 1e-4)
 
+    # ---- CSRN incl. the spatial_recurrent.py:110 overwrite
+    from scm_gan_amd.spatial_recurrent import CSRN
+    for tag, scale in (("soft", 0.5), ("sat", 8.0)):
+        cs = CSRN(8).cuda()
+        cs.load_state_dict(WS.to_torch(WS.csrn_state(6, 8, scale)))
+        xs = dev(fx["csrn_%s_x" % tag]).requires_grad_(True)
+        ys = cs(xs)
+        # "sat": N(0, 8) recurrent weights (the reference init is N(0, channels)) amplify fp32
+        # rounding ~1000x through the saturated recurrence (see tests/test_oracle_golden.py)
+        ytol, gtol = (2e-5, 2e-4) if tag == "soft" else (2e-3, 5e-3)
+        check(fx, "csrn_%s_y" % tag, ys, ytol)
+        (ys * dev(fx["csrn_%s_gy" % tag])).sum().backward()
+
+        def scaled(key):
+            return gtol * max(1.0, float(np.abs(fx[key]).max()))
+        check(fx, "csrn_%s_grad_x" % tag, xs.grad, scaled("csrn_%s_grad_x" % tag))
+        for k, p in cs.named_parameters():
+            key = "csrn_%s_grad.%s" % (tag, k)
+            check(fx, key, p.grad, scaled(key), 0.0, "csrn")
+
 
 def test_train_and_rollout_vs_reference_run(M, tmp_path, monkeypatch):
     """scm_gan_amd.main.train() + measure_prediction_mse() against the reference's
