@@ -278,11 +278,11 @@ class Trainer(object):
             active = active * (1 - dones[:, t])
             expected_reward = reward_forward(rp, z)
             rd = torch.mean(torch.mean((expected_reward - rewards[:, t]) ** 2, dim=1) * active)
-            logs.append(("Rd Loss t={}".format(t), float(rd)))
+            logs.append(("Rd Loss t={}".format(t), float(rd.detach())))
             loss = loss + theta * self.reward_coef * rd                    # main.py:185
             predicted = torch.sigmoid(decoder_forward(dec, z))
             rec = torch.mean(decoder_pixel_loss(states[:, t], predicted) * active)
-            logs.append(("Reconstruction t={}".format(t), float(rec)))
+            logs.append(("Reconstruction t={}".format(t), float(rec.detach())))
             loss = loss + rec                                              # main.py:197
             z = transition_forward(tr, z, onehot(actions[:, t], self.num_actions), True, noises[t - 1])
         loss.backward()                                                    # main.py:285
@@ -296,7 +296,7 @@ class Trainer(object):
             self.opt["enc"].step()
             self.opt["dec"].step()
             self.opt["tr"].step()
-        return float(loss), logs
+        return float(loss.detach()), logs
 
 
 def measure_prediction_mse(enc, tr, dec, rp, states, rewards, dones, actions, num_actions, return_frames=False):

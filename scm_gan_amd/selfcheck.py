@@ -44,7 +44,7 @@ def smoke():
     oz2 = O.transition_forward(otr, oz, torch.from_numpy(act), True, torch.from_numpy(noise))
     (oloss + (oz2 * 0.01).sum()).backward()
     err_z = float((z.detach().cpu() - oz.detach()).abs().max())
-    err_l = abs(float(loss) - float(oloss))
+    err_l = abs(float(loss.detach()) - float(oloss.detach()))
     flips = int((z2.detach().cpu() != oz2.detach()).sum())
     g = enc.conv2.module.weight_bar.grad.cpu()
     og = oenc["conv2.module.weight_bar"].grad
