@@ -57,12 +57,12 @@ const char* scm_last_error(void);
  *          of dy (gate = the saved forward output).
  *   acc  = conv3x3(in, W) with `pad_mode`; W is given as a weight pack made
  *          by scm_pack_conv3x3_weights (layout documented there).
- *   out  = act( acc * (*scale) + bias[co] + sbias[b][co] ) (+ addend)
- *          scale (device scalar, e.g. 1/sigma of SpectralNorm), bias, sbias
- *          and addend are optional (NULL).
+ *   out  = act( acc * (*scale) + bias[co] + sbias[b][co] )
+ *          scale (device scalar, e.g. 1/sigma of SpectralNorm), bias and sbias
+ *          are optional (NULL).
  *   The first co1 output channels go to y1[B,co1,H,W], the remaining
- *   cout-co1 to y2[B,cout-co1,H,W] (y2 may be NULL when co1 == cout); co1
- *   must be a multiple of 32 when y2 is used.
+ *   cout-co1 to y2[B,cout-co1,H,W] (y2 may be NULL when co1 == cout): this is
+ *   how the input-gradient conv of a two-input layer writes dx1 and dx2.
  * ---------------------------------------------------------------------- */
 typedef struct scm_conv3x3_desc {
     const float* x1; const float* x2; int32_t c1; int32_t c2;
