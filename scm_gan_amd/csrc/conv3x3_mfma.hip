@@ -18,6 +18,7 @@
 // [KC][rows+2][W+2] and the weight slab [KC][9][32][CT] are staged in LDS; the
 // im2col is only an address offset (ky*(W+2)+kx) into the halo tile.
 #include "common.h"
+#include <type_traits>
 
 #define KC 8
 #define MAXJ 8
@@ -51,8 +52,8 @@ __global__ void __launch_bounds__(256, 1) conv3x3_mfma_kernel(const ConvKArgs a)
     constexpr int NPW = PT * 32, NP = 4 * NPW;
     constexpr int PLANE = NJ * 256;                // fixed LDS plane pitch: every thread writes NJ slots, no branches
     constexpr int WLDS = WR * 256 * 4;             // weight region padded to whole thread passes
-    float* wl = smem;
-    float* xl = smem + WLDS;
+    constexpr int BUF = WLDS + KC * PLANE;         // floats per LDS stage
+    constexpr bool DB = (NJ == 4);                 // two LDS stages when they fit in 160 KB
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -148,7 +149,9 @@ __global__ void __launch_bounds__(256, 1) conv3x3_mfma_kernel(const ConvKArgs a)
             }
         }
     };
-    auto store = [&](int ci0) {
+    auto store = [&](int ci0, int buf) {
+        float* wl = smem + buf * BUF;
+        float* xl = wl + WLDS;
 #pragma unroll
         for (int k = 0; k < WR; ++k) {
             const int i = tid + 256 * k;
@@ -171,16 +174,13 @@ __global__ void __launch_bounds__(256, 1) conv3x3_mfma_kernel(const ConvKArgs a)
         }
     };
 
-    fetch(0);
-    for (int ci0 = 0; ci0 < cin; ci0 += KC) {
-        __syncthreads();                 // the previous chunk's MFMAs are done with the tiles
-        store(ci0);
-        __syncthreads();
-        if (ci0 + KC < cin) fetch(ci0 + KC);   // flies under this chunk's MFMAs
-
-        // ---- MFMA over the chunk: 9 taps x KC/2 k-steps
+    // MFMA over taps [t0, t1) of the chunk staged in LDS buffer `buf`
+    auto mfma_taps = [&](int buf, auto t0c, auto t1c) {
+        const float* wl = smem + buf * BUF;
+        const float* xl = wl + WLDS;
+        constexpr int T0 = decltype(t0c)::value, T1 = decltype(t1c)::value;
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
+        for (int tap = T0; tap < T1; ++tap) {
             const int toff = (tap / 3) * ROWPL + (tap % 3);
 #pragma unroll
             for (int ks = 0; ks < KC / 2; ++ks) {
@@ -205,26 +205,81 @@ __global__ void __launch_bounds__(256, 1) conv3x3_mfma_kernel(const ConvKArgs a)
                         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[n], acc[m][n], 0, 0, 0);
             }
         }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I4 = std::integral_constant<int, 4>;
+    using I9 = std::integral_constant<int, 9>;
+
+    if constexpr (DB) {
+        // Two LDS stages: chunk k+1 is written into the idle stage in the middle of chunk
+        // k's MFMAs (its loads were issued a whole chunk earlier), then chunk k+2's loads
+        // are issued; one barrier per chunk.
+        fetch(0);
+        store(0, 0);
+        if (KC < cin) fetch(KC);
+        __syncthreads();
+        int cur = 0;
+        for (int ci0 = 0; ci0 < cin; ci0 += KC) {
+            mfma_taps(cur, I0{}, I4{});
+            if (ci0 + KC < cin) store(ci0 + KC, cur ^ 1);
+            if (ci0 + 2 * KC < cin) fetch(ci0 + 2 * KC);
+            mfma_taps(cur, I4{}, I9{});
+            __syncthreads();
+            cur ^= 1;
+        }
+    } else {
+        fetch(0);
+        for (int ci0 = 0; ci0 < cin; ci0 += KC) {
+            __syncthreads();                 // the previous chunk's MFMAs are done with the tiles
+            store(ci0, 0);
+            __syncthreads();
+            if (ci0 + KC < cin) fetch(ci0 + KC);   // flies under this chunk's MFMAs
+            mfma_taps(0, I0{}, I9{});
+        }
     }
 
-    // ---- epilogue: scale, bias, per-sample bias, activation, NCHW store
+    // ---- epilogue: scale, bias, per-sample bias, activation, NCHW store.
+    // The 16*CT bias values of this lane are loaded first, unconditionally (clamped
+    // index) and all in flight together: loading bias[co] inside the guarded store
+    // loop cost one serialized L2 round trip per accumulator register (45 us / WG).
     const float sc = a.scale ? *a.scale : 1.f;
     const int co2n = a.cout - a.co1;
+    float badd[CT][16];
+#pragma unroll
+    for (int m = 0; m < CT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) badd[m][r] = 0.f;
+    if (a.bias) {
+#pragma unroll
+        for (int m = 0; m < CT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = cg * CW + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                badd[m][r] += a.bias[co < a.cout ? co : a.cout - 1];
+            }
+    }
+    if (a.sbias) {
+#pragma unroll
+        for (int m = 0; m < CT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = cg * CW + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                badd[m][r] += a.sbias[(size_t)b * a.cout + (co < a.cout ? co : a.cout - 1)];
+            }
+    }
+    const int pbase = p0 + wave * NPW + l31;
 #pragma unroll
     for (int m = 0; m < CT; ++m) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = cg * CW + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             if (co < a.cout) {
-                float add = 0.f;
-                if (a.bias) add += a.bias[co];
-                if (a.sbias) add += a.sbias[(size_t)b * a.cout + co];
                 float* dst = co < a.co1 ? a.y1 + ((size_t)b * a.co1 + co) * HW
                                         : a.y2 + ((size_t)b * co2n + (co - a.co1)) * HW;
 #pragma unroll
                 for (int n = 0; n < PT; ++n) {
-                    const int p = p0 + wave * NPW + n * 32 + l31;
-                    if (p < HW) dst[p] = scm_act(acc[m][n][r] * sc + add, a.act);
+                    const int p = pbase + n * 32;
+                    if (p < HW) dst[p] = scm_act(acc[m][n][r] * sc + badd[m][r], a.act);
                 }
             }
         }
@@ -309,7 +364,7 @@ extern "C" int scm_pack_conv3x3_weights(const float* w, int cin, int cout, int t
 template <int CT, int PT, int NJ, bool GATED>
 static int launch_conv_nj(const ConvKArgs& a, int groups, hipStream_t s) {
     constexpr int W4 = KC * 9 * CT * 32 / 4, WR = (W4 + 255) / 256;
-    const size_t lds = ((size_t)WR * 256 * 4 + (size_t)KC * NJ * 256) * sizeof(float);
+    const size_t lds = ((size_t)WR * 256 * 4 + (size_t)KC * NJ * 256) * sizeof(float) * (NJ == 4 ? 2 : 1);
     auto kern = conv3x3_mfma_kernel<CT, PT, NJ, GATED>;
     static bool attr_set = false;
     if (!attr_set) {
