@@ -215,8 +215,15 @@ def main():
             dom = max(summ.items(), key=lambda kv: kv[1]["ms"])
             name, s = dom
             achieved = s["flops"] / (s["ms"] * 1e-3) / 1e12
+            traffic = None       # HBM bytes per launch from the committed PMC passes (profiles/round1_pmc.json)
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc.json")))["kernels"]
+                key = [k for k in pmc if name.split("<")[0] in k and "false" in k]
+                traffic = pmc[key[0]]["hbm_traffic_bytes"] if key else None
+            except Exception:
+                pass
             out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
-                               "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                               "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                                "launches": s["launches"], "avg_launch_us": s["ms"] * 1e3 / s["launches"],
                                "share_of_step": s["ms"] / (dt * 1e3)}
             out["kernels"] = {k: {"launches": v["launches"], "ms_total": round(v["ms"], 3),
