@@ -156,7 +156,10 @@ def main():
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % a.gpus)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    under_launcher = "RANK" in os.environ and "MASTER_PORT" in os.environ
+    if world > 1 or under_launcher:
+        # one process per GPU, RCCL (backend "nccl" on ROCm); also taken for a 1-rank launch
+        # under torch.distributed.run so that path is exercised on a single-GPU box
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=dev)
@@ -172,7 +175,7 @@ def main():
     batches = [make_batch(ds, a.batch, a.horizon, dev) for _ in range(2)]    # resident in HBM
 
     def barrier():
-        if world > 1:
+        if world > 1 or under_launcher:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
@@ -190,7 +193,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     ops.kernel_timer = None
-    if world > 1:
+    if world > 1 or under_launcher:
         import torch.distributed as dist
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -235,7 +238,7 @@ def main():
             if not a.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or under_launcher:
         import torch.distributed as dist
         dist.destroy_process_group()
 

@@ -328,6 +328,21 @@ def measure_prediction_mse(enc, tr, dec, rp, states, rewards, dones, actions, nu
         return out
 
 
+def compute_rollout_reward(z, tr, rp, num_actions, lookahead=2, rollout_depth=12, negative_positive_tradeoff=10.0):
+    """main.compute_rollout_reward, main.py:455-489 (rollout_policy='noop'), eval mode."""
+    with torch.no_grad():
+        width = num_actions ** lookahead
+        z = z.repeat(width, 1, 1, 1)
+        actions = np.array([[i, j] + [0] * (rollout_depth - lookahead) for i in range(num_actions)
+                            for j in range(num_actions)])
+        cum = reward_forward(rp, z)
+        for t in range(rollout_depth):
+            z = transition_forward(tr, z, onehot(actions[:, t], num_actions), False)
+            cum = cum + reward_forward(rp, z)
+        cum[:, 0] *= negative_positive_tradeoff
+        return cum.sum(dim=1).max(dim=0)[0], cum
+
+
 def clone_state(np_state):
     """numpy state dict (tests/golden/weights.py) -> fresh torch state."""
     return {k: torch.from_numpy(np.array(v)).clone() for k, v in np_state.items()}

@@ -272,7 +272,7 @@ class Trainer(object):
 
         loss.backward()                                                        # main.py:285
 
-        if self.world > 1:
+        if self.world > 1 or os.environ.get("SCM_FORCE_ALLREDUCE") == "1":
             for f in self.flats:
                 f.all_reduce()      # sum over ranks; AdamClip applies 1/world before the clip
 

@@ -414,6 +414,61 @@ def gen_train(out, seed, H=16, W=16, B=4, horizon=5, iters=3):
     print("train_rollout.npz: %d arrays, %d losses, %d noise draws" % (len(fx), len(_TimeSeries.log), len(rb.draws)))
 
 
+def gen_train_flags(out, seed):
+    """The optional loss terms of the reference's train() (main.py:192-193,217-234,
+    242-283): one short run per flag set, same data / noise protocol as gen_train."""
+    import main as ref_main
+    import models
+    from scm_gan_amd.datasource import SyntheticDatasource
+    A, R, C, L = 5, 2, 3, 16
+    H = W = 12
+    B = 4
+    fx = {}
+    cases = {
+        # --truncate-bptt cannot be pinned: the reference z.detach_() (main.py:193) raises on torch 2.x
+        # ("saved tensor ... detached in-place"); the build implements it as an out-of-place detach.
+        "lo": dict(iters=2, horizon=6, latent_overshooting=True),
+        "cf": dict(iters=5, horizon=5, enable_disentanglement_loss=True, enable_action_control_loss=True,
+                   counterfactual_horizon=3),
+    }
+    for name, cfg in cases.items():
+        ds = SyntheticDatasource(seed=seed + 5, height=H, width=W, channels=C, num_actions=A, num_rewards=R,
+                                 done_every=3)
+        enc, dec, rp, disc = models.Encoder(L, C), models.Decoder(L, C), models.RewardPredictor(L, R), \
+            models.Discriminator()
+        with circular_pad1():
+            tr = models.Transition(L, A)
+        enc.load_state_dict(WS.to_torch(WS.encoder_state(seed + 30)))
+        tr.load_state_dict(WS.to_torch(WS.transition_state(seed + 31)))
+        dec.load_state_dict(WS.to_torch(WS.decoder_state(seed + 32)))
+        rp.load_state_dict(WS.to_torch(WS.reward_state(seed + 33)))
+        a = ref_main.args
+        a.batch_size, a.train_iters, a.horizon_min, a.horizon_max = B, cfg["iters"], cfg["horizon"], cfg["horizon"]
+        a.truncate_bptt = cfg.get("truncate_bptt", False)
+        a.latent_overshooting = cfg.get("latent_overshooting", False)
+        a.counterfactual_horizon = cfg.get("counterfactual_horizon", 1)
+        # these two are module-level copies in the reference (main.py:57-58)
+        ref_main.enable_cf_shuffle_loss = cfg.get("enable_disentanglement_loss", False)
+        ref_main.enable_control_bias_loss = cfg.get("enable_action_control_loss", False)
+        _TimeSeries.log = []
+        np.random.seed(1234)
+        with recorded_bernoulli(7000 + seed) as rb:
+            ref_main.train(L, ds, A, R, enc, dec, rp, disc, tr)
+        fx[name + ".cfg"] = np.array([B, H, W, cfg["horizon"], cfg["iters"], cfg.get("counterfactual_horizon", 1)], np.int64)
+        fx[name + ".noise_shapes"] = np.array([d.shape[0] for d in rb.draws], np.int64)
+        fx[name + ".loss_names"] = np.array([n for n, _ in _TimeSeries.log])
+        fx[name + ".loss_values"] = np.array([v for _, v in _TimeSeries.log], np.float64)
+        for mname, m in (("enc", enc), ("tr", tr), ("dec", dec), ("rp", rp)):
+            for k, v in m.state_dict().items():
+                if v.dtype.is_floating_point:
+                    fx["%s.final.%s.%s" % (name, mname, k)] = WS.digest(npy(v))
+        print(name, len(_TimeSeries.log), "losses,", len(rb.draws), "noise draws")
+    a.truncate_bptt = a.latent_overshooting = False
+    a.counterfactual_horizon = 1
+    ref_main.enable_cf_shuffle_loss = ref_main.enable_control_bias_loss = False
+    np.savez_compressed(os.path.join(out, "train_flags.npz"), **fx)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=HERE)
@@ -431,6 +486,8 @@ def main():
         gen_operators(a.out, a.seed)
     if a.only in ("", "train"):
         gen_train(a.out, a.seed)
+    if a.only in ("", "flags"):
+        gen_train_flags(a.out, a.seed)
 
 
 if __name__ == "__main__":

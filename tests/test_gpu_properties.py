@@ -1,0 +1,120 @@
+"""GPU (-m gpu): size-independent properties of the HIP conv path at BASELINE.json's
+full sizes (configs[1]: B=64, 64x64, 128 channels; configs[3]/[4] shapes 84x84 and
+128x128x4), plus oracle checks on slices of the full-size batch."""
+import numpy as np
+import pytest
+import torch
+
+import weights as WS
+
+pytestmark = pytest.mark.gpu
+
+
+def dot(a, b):
+    return float((a.double() * b.double()).sum())
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from scm_gan_amd import ops as O
+    return O
+
+
+def conv(ops, x, w, b, pad, act=0, x2=None):
+    cin = x.shape[1] + (0 if x2 is None else x2.shape[1])
+    cfg = {"pad": pad, "act": act, "transposed": False, "packs": ops.pack_conv3x3(w, cin, w.shape[0])}
+    return ops.Conv3x3Fn.apply(x, x2, None, w, b, None, None, None, cfg)
+
+
+@pytest.mark.parametrize("pad", [0, 1])
+def test_adjoint_identities_full_size(ops, pad):
+    """<conv(x), dy> == <x, dgrad(dy)> == <W, wgrad(x, dy)> at B=64, 128->128, 64x64."""
+    torch.manual_seed(0)
+    B, C, H, W = 64, 128, 64, 64
+    x = torch.randn(B, C, H, W, device="cuda", requires_grad=True)
+    w = (torch.randn(128, C, 3, 3, device="cuda") * 0.05).requires_grad_(True)
+    dy = torch.randn(B, 128, H, W, device="cuda")
+    y = conv(ops, x, w, None, pad)
+    y.backward(dy)
+    lhs = dot(y.detach(), dy)
+    assert abs(lhs - dot(x.detach(), x.grad)) < 2e-5 * abs(lhs)
+    assert abs(lhs - dot(w.detach(), w.grad)) < 2e-5 * abs(lhs)
+
+
+def test_circular_shift_equivariance_full_size(ops):
+    """circular padding: conv(roll(x)) == roll(conv(x)) (toroidal symmetry), 256->128 two-input form."""
+    torch.manual_seed(1)
+    B, H, W = 64, 64, 64
+    x1 = torch.randn(B, 128, H, W, device="cuda")
+    x2 = torch.randn(B, 128, H, W, device="cuda")
+    w = torch.randn(128, 256, 3, 3, device="cuda") * 0.05
+    b = torch.randn(128, device="cuda")
+    y = conv(ops, x1, w, b, 1, act=1, x2=x2)
+    ys = conv(ops, torch.roll(x1, (5, -7), (2, 3)).contiguous(), w, b, 1, act=1,
+              x2=torch.roll(x2, (5, -7), (2, 3)).contiguous())
+    assert torch.equal(torch.roll(y, (5, -7), (2, 3)), ys)      # same summation order -> bit-identical
+
+
+def test_linearity_and_batch_independence(ops):
+    torch.manual_seed(2)
+    x1 = torch.randn(64, 128, 64, 64, device="cuda")
+    x2 = torch.randn(64, 128, 64, 64, device="cuda")
+    w = torch.randn(128, 128, 3, 3, device="cuda") * 0.05
+    ya, yb = conv(ops, x1, w, None, 0), conv(ops, x2, w, None, 0)
+    yc = conv(ops, 2 * x1 + x2, w, None, 0)
+    assert float((yc - (2 * ya + yb)).abs().max()) < 2e-4
+    # a sample's output does not depend on its batch neighbours (bitwise)
+    y3 = conv(ops, x1[3:4].contiguous(), w, None, 0)
+    assert torch.equal(y3[0], ya[3])
+
+
+def test_backward_is_bitwise_reproducible(ops):
+    """split reductions run in a fixed order (no float atomics)."""
+    torch.manual_seed(3)
+    x = torch.randn(16, 128, 64, 64, device="cuda")
+    w = (torch.randn(128, 128, 3, 3, device="cuda") * 0.05)
+    b = torch.zeros(128, device="cuda")
+    dy = torch.randn(16, 128, 64, 64, device="cuda")
+    grads = []
+    for _ in range(2):
+        wi, bi = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        conv(ops, x, wi, bi, 1, act=1).backward(dy)
+        grads.append((wi.grad.clone(), bi.grad.clone()))
+    assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1])
+
+
+@pytest.mark.parametrize("shape", [(64, 64, 3, 5, 2), (84, 84, 3, 4, 1), (128, 128, 4, 4, 2)])
+def test_full_size_step_slices_vs_oracle(shape):
+    """Encoder -> decoder / reward head -> transition at the BASELINE frame sizes; two
+    samples of the batch are checked against the CPU oracle (fp32, 1e-4)."""
+    from oracle import scm_oracle as O
+    from scm_gan_amd import models as M
+    H, W, C, A, R = shape
+    B = 8
+    rng = np.random.default_rng(H)
+    frames = (rng.random((B, 3, C, H, W)) < 0.1).astype(np.float32)
+    act = np.zeros((B, A), np.float32)
+    act[np.arange(B), rng.integers(0, A, B)] = 1
+    states = [WS.encoder_state(60, color=C), WS.transition_state(61, actions=A), WS.decoder_state(62, color=C),
+              WS.reward_state(63, rewards=R)]
+    enc, tr, dec, rp = M.Encoder(16, C), M.Transition(16, A), M.Decoder(16, C), M.RewardPredictor(16, R)
+    for m, s in zip((enc, tr, dec, rp), states):
+        m.load_state_dict(WS.to_torch(s))
+        m.eval()
+    with torch.no_grad():
+        z = enc(torch.from_numpy(frames).cuda())
+        y = dec(z)
+        r = rp(z)
+        z2 = tr(z, torch.from_numpy(act).cuda())
+    oenc, otr, odec, orp = (O.clone_state(s) for s in states)
+    sl = [0, B - 1]
+    with torch.no_grad():
+        oz = O.encoder_forward(oenc, torch.from_numpy(frames[sl]))
+        oy = O.decoder_forward(odec, oz)
+        orr = O.reward_forward(orp, oz)
+        oz2, ologit = O.transition_forward(otr, oz, torch.from_numpy(act[sl]), False, return_logits=True)
+    assert float((z[sl].cpu() - oz).abs().max()) < 1e-4
+    assert float((y[sl].cpu() - oy).abs().max()) < 1e-4 * max(1.0, float(oy.abs().max()))
+    assert float((r[sl].cpu() - orr).abs().max()) < 1e-3 * max(1.0, float(orr.abs().max()))
+    safe = ologit.abs() > 1e-5
+    assert torch.equal(z2[sl].cpu()[safe], oz2[safe])
