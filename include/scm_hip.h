@@ -107,8 +107,8 @@ int scm_pack_conv3x3_weights(const float* w, int cin, int cout, int transposed_s
  *   csum[b][co]        =  sum_{y,x} dyp[b,co,y,x]          (optional)
  *   db[co]             (=|+=) sum_b csum[b][co]            (optional)
  * `in` is concat(x1, x2) as in scm_conv3x3.  transposed_dst = 1 writes the
- * nn.ConvTranspose2d layout dw[ci][co][2-ky][2-kx].  accumulate = 1 adds into
- * dw / db instead of overwriting.  part_ws / csum_ws are caller-provided
+ * nn.ConvTranspose2d layout dw[ci][co][2-ky][2-kx].  accumulate: bit 0 adds into
+ * dw, bit 1 adds into db, instead of overwriting.  part_ws / csum_ws are caller-provided
  * workspaces sized by scm_conv3x3_wgrad_workspace (split-K partial slabs,
  * reduced in a fixed order: results are bitwise reproducible).
  * ---------------------------------------------------------------------- */

@@ -418,13 +418,13 @@ extern "C" int scm_conv3x3_wgrad(const scm_conv3x3_wgrad_desc* d, void* stream) 
     const int total = 9 * d->cout * cin;
     const int dct = d->dw_cin_total ? d->dw_cin_total : cin;
     SCM_REQUIRE(d->dw_ci0 >= 0 && d->dw_ci0 + cin <= dct, "scm_conv3x3_wgrad: bad dw channel slice");
-    SCM_REQUIRE(!d->dot_w || (d->dot_part && !d->accumulate), "scm_conv3x3_wgrad: dot_w needs dot_part and accumulate == 0");
+    SCM_REQUIRE(!d->dot_w || (d->dot_part && !(d->accumulate & 1)), "scm_conv3x3_wgrad: dot_w needs dot_part and no dw accumulation");
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, d->part_ws, p.nsplit, d->cout,
-                       cin, d->transposed_dst, d->accumulate, dct, d->dw_ci0, d->dw, d->dot_w, d->dot_w ? d->dot_part : nullptr);
+                       cin, d->transposed_dst, d->accumulate & 1, dct, d->dw_ci0, d->dw, d->dot_w, d->dot_w ? d->dot_part : nullptr);
     SCM_LAUNCH_CHECK("wgrad_reduce_kernel");
     if (want_cs) {
         hipLaunchKernelGGL(csum_reduce_kernel, dim3((d->cout + 63) / 64), dim3(1024), 0, s, d->csum_ws, d->B, p.spi,
-                           d->cout, d->accumulate, d->csum, d->db);
+                           d->cout, (d->accumulate >> 1) & 1, d->csum, d->db);
         SCM_LAUNCH_CHECK("csum_reduce_kernel");
     }
     return SCM_OK;

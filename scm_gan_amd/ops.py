@@ -138,15 +138,31 @@ def sn_power_iter_multi(layers, steps):
     return out
 
 
-def _sn_fold(g, weight_bar, u, v, inv_sigma, dot_part=None):
+def _sn_fold(g, weight_bar, u, v, inv_sigma, dot_part=None, into=None):
+    """dW_bar from dW_eff; `into` = an existing gradient buffer to accumulate into."""
     lib = L.lib()
     rows = weight_bar.shape[0]
     cols = weight_bar.numel() // rows
-    out = torch.empty_like(g)
+    out = torch.empty_like(g) if into is None else into
     ndot = 0 if dot_part is None else dot_part.numel()
-    L.check(lib.scm_sn_fold_grad(_p(g), _p(weight_bar), _p(u), _p(v), _p(inv_sigma), _p(dot_part), ndot, rows, cols, 0,
-                                 _p(out), _stream()), "scm_sn_fold_grad")
+    L.check(lib.scm_sn_fold_grad(_p(g), _p(weight_bar), _p(u), _p(v), _p(inv_sigma), _p(dot_part), ndot, rows, cols,
+                                 0 if into is None else 1, _p(out), _stream()), "scm_sn_fold_grad")
     return out
+
+
+# When a parameter already owns a contiguous .grad buffer (Trainer's flat buckets), the
+# backward kernels accumulate into it directly and hand autograd no gradient for that
+# parameter: saves one elementwise add launch per parameter per timestep.
+accumulate_in_kernel = True
+
+
+def _grad_sink(param):
+    if not accumulate_in_kernel or param is None or not isinstance(param, torch.nn.Parameter):
+        return None
+    g = param.grad
+    if g is None or not g.is_contiguous() or g.dtype != torch.float32 or not g.is_cuda:
+        return None
+    return g
 
 
 # -------------------------------------------------------------- conv 3x3
@@ -182,6 +198,7 @@ class Conv3x3Fn(Function):
         ctx.cfg = cfg
         ctx.shape = (B, c1, c2, H, W, cout, cin_total)
         ctx.has = (x2 is not None, act_vec is not None, bias is not None, inv_sigma is not None)
+        ctx.params = (weight, bias)          # the Parameter objects: their .grad is looked up at backward time
         ctx.save_for_backward(x1, x2, act_vec, w, inv_sigma, u, v, y, dpack)
         return y
 
@@ -205,9 +222,12 @@ class Conv3x3Fn(Function):
             part = _new(gy, pf.value)
             cws = _new(gy, cf.value)
             has_act = act_vec is not None
+            w_sink, b_sink = _grad_sink(ctx.params[0]), _grad_sink(ctx.params[1])
+            direct_w = w_sink is not None and inv_sigma is None and not has_act    # reduce straight into .grad
             # dw_eff: gradient w.r.t. the effective weight, in the parameter's layout
-            dw_eff = torch.empty_like(w)
-            db = _new(gy, cout)
+            dw_eff = w_sink if direct_w else torch.empty_like(w)
+            db = b_sink if b_sink is not None else _new(gy, cout)
+            acc_flag = (1 if direct_w else 0) | (2 if b_sink is not None else 0)
             csum = _new(gy, B, cout) if has_act else None
             # <dW_eff, W_bar> partials for the SpectralNorm fold come out of the reduce kernel
             # (not when action channels add their slice afterwards: the fold then does the dot itself)
@@ -215,7 +235,7 @@ class Conv3x3Fn(Function):
             if inv_sigma is not None and not has_act:
                 dot_part = _new(gy, (9 * cout * (c1 + c2) + 255) // 256)
             d = L.WgradDesc(_p(x1), _p(x2), c1, c2, _p(gy), _p(y) if act else None, act, cout, _p(dw_eff), _p(db),
-                            _p(csum), _p(part), _p(cws), B, H, W, cfg["pad"], int(cfg["transposed"]), 0,
+                            _p(csum), _p(part), _p(cws), B, H, W, cfg["pad"], int(cfg["transposed"]), acc_flag,
                             cin_total, 0, _p(w) if dot_part is not None else None, _p(dot_part))
             L.check(lib.scm_conv3x3_wgrad(ctypes.byref(d), _stream()), "scm_conv3x3_wgrad")
             if has_act:
@@ -224,9 +244,13 @@ class Conv3x3Fn(Function):
                 L.check(lib.scm_action_bias_bwd(_p(act_vec), _p(w), _p(inv_sigma), _p(csum), B, A, cout, cin_total,
                                                 c1 + c2, _p(d_act), _p(dw_eff), _stream()), "scm_action_bias_bwd")
             if inv_sigma is not None:
-                dw = _sn_fold(dw_eff, w, u, v, inv_sigma, dot_part)
+                dw = _sn_fold(dw_eff, w, u, v, inv_sigma, dot_part, into=w_sink)
             else:
                 dw = dw_eff
+            if w_sink is not None:
+                dw = None                # already accumulated into weight.grad
+            if b_sink is not None:
+                db = None
         return (dx1 if need_x1 else None, dx2 if need_x2 else None, d_act if need_a else None,
                 dw if need_w else None, db if need_b else None, None, None, None, None)
 
