@@ -19,6 +19,7 @@
 // im2col is only an address offset (ky*(W+2)+kx) into the halo tile.
 #include "common.h"
 #include <type_traits>
+#include <stdlib.h>
 
 #define KC 8
 #define MAXJ 8
@@ -41,8 +42,8 @@ struct ConvKArgs {
 //   issue the next chunk's global loads into registers | 36 x CT*PT MFMAs
 // Every global load is unconditional on a clamped address (a load under a
 // per-lane condition makes hipcc branch around it and serialise the loads).
-template <int CT, int PT, int NJ, bool GATED>
-__global__ void __launch_bounds__(256, 1) conv3x3_mfma_kernel(const ConvKArgs a) {
+template <int CT, int PT, int NJ, bool GATED, int WPS = 1>
+__global__ void __launch_bounds__(256, WPS) conv3x3_mfma_kernel(const ConvKArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int CW = CT * 32;
     constexpr int WCHUNK = KC * 9 * CW;
@@ -53,7 +54,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_mfma_kernel(const ConvKArgs a)
     constexpr int PLANE = NJ * 256;                // fixed LDS plane pitch: every thread writes NJ slots, no branches
     constexpr int WLDS = WR * 256 * 4;             // weight region padded to whole thread passes
     constexpr int BUF = WLDS + KC * PLANE;         // floats per LDS stage
-    constexpr bool DB = (NJ == 4);                 // two LDS stages when they fit in 160 KB
+    constexpr bool DB = (NJ == 4) && WPS == 1;     // two LDS stages when they fit in 160 KB (one WG per CU)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -361,11 +362,11 @@ extern "C" int scm_pack_conv3x3_weights(const float* w, int cin, int cout, int t
     return SCM_OK;
 }
 
-template <int CT, int PT, int NJ, bool GATED>
+template <int CT, int PT, int NJ, bool GATED, int WPS = 1>
 static int launch_conv_nj(const ConvKArgs& a, int groups, hipStream_t s) {
     constexpr int W4 = KC * 9 * CT * 32 / 4, WR = (W4 + 255) / 256;
-    const size_t lds = ((size_t)WR * 256 * 4 + (size_t)KC * NJ * 256) * sizeof(float) * (NJ == 4 ? 2 : 1);
-    auto kern = conv3x3_mfma_kernel<CT, PT, NJ, GATED>;
+    const size_t lds = ((size_t)WR * 256 * 4 + (size_t)KC * NJ * 256) * sizeof(float) * ((NJ == 4 && WPS == 1) ? 2 : 1);
+    auto kern = conv3x3_mfma_kernel<CT, PT, NJ, GATED, WPS>;
     static bool attr_set = false;
     if (!attr_set) {
         int rc = scm_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -394,6 +395,12 @@ static int launch_conv(const ConvKArgs& k, int groups, hipStream_t s) {
     if (rows > a.H) rows = a.H;
     a.plane = (rows + 2) * (a.W + 2);
     const bool gated = a.gate_act != 0;
+    if constexpr (CT == 4 && PT == 2) {
+        if (a.plane <= 2 * 256)
+            return gated ? launch_conv_nj<4, 2, 2, true, 2>(a, groups, s) : launch_conv_nj<4, 2, 2, false, 2>(a, groups, s);
+        scm_set_error("scm_conv3x3: 2-WG/CU variant needs a halo tile <= 512 elements");
+        return SCM_EUNSUPPORTED;
+    }
     if (a.plane <= 4 * 256)
         return gated ? launch_conv_nj<CT, PT, 4, true>(a, groups, s) : launch_conv_nj<CT, PT, 4, false>(a, groups, s);
     if (a.plane <= MAXJ * 256)
@@ -428,7 +435,16 @@ extern "C" int scm_conv3x3(const scm_conv3x3_desc* d, void* stream) {
     const int ct = conv_ct(d->cout);
     const int groups = (d->cout + ct * 32 - 1) / (ct * 32);
     hipStream_t s = (hipStream_t)stream;
-    if (ct == 4) return launch_conv<4, 4>(k, groups, s);
+    if (ct == 4) {
+        // Two workgroups per CU (256-pixel tiles, <= 256 VGPRs) let one workgroup's epilogue
+        // stores and staging bubbles hide under the other's MFMAs: +4..6 % over the 512-pixel
+        // one-wave-per-SIMD tile when the halo tile fits 512 LDS slots (W = 64 images).
+        static const int one_wg = getenv("SCM_CONV_1WG") ? atoi(getenv("SCM_CONV_1WG")) : 0;
+        int rows = (256 % d->W == 0) ? 256 / d->W : (256 + d->W - 2) / d->W + 1;
+        if (rows > d->H) rows = d->H;
+        if (!one_wg && (rows + 2) * (d->W + 2) <= 512) return launch_conv<4, 2>(k, groups, s);
+        return launch_conv<4, 4>(k, groups, s);
+    }
     if (ct == 2) return launch_conv<2, 4>(k, groups, s);
     return launch_conv<1, 8>(k, groups, s);
 }
