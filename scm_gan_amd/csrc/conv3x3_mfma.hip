@@ -398,7 +398,9 @@ static int launch_conv(const ConvKArgs& k, int groups, hipStream_t s) {
     if constexpr (CT == 4 && PT == 2) {
         if (a.plane <= 2 * 256)
             return gated ? launch_conv_nj<4, 2, 2, true, 2>(a, groups, s) : launch_conv_nj<4, 2, 2, false, 2>(a, groups, s);
-        scm_set_error("scm_conv3x3: 2-WG/CU variant needs a halo tile <= 512 elements");
+        if (a.plane <= 3 * 256)
+            return gated ? launch_conv_nj<4, 2, 3, true, 2>(a, groups, s) : launch_conv_nj<4, 2, 3, false, 2>(a, groups, s);
+        scm_set_error("scm_conv3x3: 2-WG/CU variant needs a halo tile <= 768 elements");
         return SCM_EUNSUPPORTED;
     }
     if (a.plane <= 4 * 256)
@@ -442,7 +444,7 @@ extern "C" int scm_conv3x3(const scm_conv3x3_desc* d, void* stream) {
         static const int one_wg = getenv("SCM_CONV_1WG") ? atoi(getenv("SCM_CONV_1WG")) : 0;
         int rows = (256 % d->W == 0) ? 256 / d->W : (256 + d->W - 2) / d->W + 1;
         if (rows > d->H) rows = d->H;
-        if (!one_wg && (rows + 2) * (d->W + 2) <= 512) return launch_conv<4, 2>(k, groups, s);
+        if (!one_wg && (rows + 2) * (d->W + 2) <= 768) return launch_conv<4, 2>(k, groups, s);
         return launch_conv<4, 4>(k, groups, s);
     }
     if (ct == 2) return launch_conv<2, 4>(k, groups, s);

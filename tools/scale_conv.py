@@ -15,3 +15,6 @@ def run(B, cin, cout=128, H=64, W=64, act=1, n=8):
 for B in (16, 32, 64, 128, 256): run(B, 128)
 for cin in (8, 16, 32, 64, 128, 256, 512): run(32, cin)
 for cin in (8, 64, 128): run(64, cin)
+print('--- other widths'); sys.stdout.flush()
+run(16, 128, H=128, W=128)
+run(36, 128, H=84, W=84)
