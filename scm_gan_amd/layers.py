@@ -109,6 +109,21 @@ class ConvTranspose3x3(nn.Module):
         return ops.Conv3x3Fn.apply(x, None, None, w, self.bias, None, None, None, cfg)
 
 
+def _convT_factor_sum(self, x, L, C):
+    """ConvTranspose3x3 followed by the Decoder's factor sum (models.py:278-287), with
+    the sum folded into the weights: out channel c uses sum_f W[:, f*C + c]."""
+    w = self.weight                                   # (cin, L*C, 3, 3)
+    cin = w.shape[0]
+    ws = ops.FactorSumFn.apply(w.reshape(cin, L * C, 3, 3), L, C)                    # (cin, C, 3, 3)
+    bs = ops.FactorSumFn.apply(self.bias.reshape(1, L * C, 1, 1), L, C).reshape(C)   # (C,)
+    packs = ops.pack_conv3x3(ws, cin, C, True, cin, 0)
+    cfg = {"pad": ops.PAD_ZERO, "act": ops.ACT_NONE, "transposed": True, "packs": packs}
+    return ops.Conv3x3Fn.apply(x, None, None, ws, bs, None, None, None, cfg)
+
+
+ConvTranspose3x3.forward_factor_sum = _convT_factor_sum
+
+
 class Linear(nn.Module):
     """nn.Linear look-alike for the Discriminator head (models.py:205)."""
 

@@ -156,8 +156,12 @@ class Decoder(nn.Module):
     def forward(self, z_map, visualize=False):
         batch_size, latent_size, height, width = z_map.shape
         x = self.conv1(z_map, act=ops.ACT_LRELU)
-        x = self.conv2(x)
-        out = ops.FactorSumFn.apply(x, latent_size, self.color_channels)
         if visualize:
+            # the per-factor maps are wanted: materialise conv2's latent_size*C channels (models.py:278-290)
+            x = self.conv2(x)
+            out = ops.FactorSumFn.apply(x, latent_size, self.color_channels)
             return out, x.view(batch_size, latent_size, self.color_channels, height, width)[0]
-        return out
+        # x.view(B, L, C, H, W).sum(1) of a linear conv == the conv with its weights (and bias) summed
+        # over the L factors: conv2 shrinks from 64 -> L*C to 64 -> C output channels, forward and
+        # backward (its weight gradient is the broadcast of the summed-weight gradient: FactorSumFn).
+        return self.conv2.forward_factor_sum(x, latent_size, self.color_channels)
