@@ -21,19 +21,7 @@
 #include <type_traits>
 #include <stdlib.h>
 
-#define KC 8
-#define MAXJ 8
-
-struct ConvKArgs {
-    const float* x1; const float* x2; int c1; int c2;
-    const float* gate1; const float* gate2; int gate_act;
-    const float* wpack; int cout;
-    const float* scale; const float* bias; const float* sbias;
-    float* y1; float* y2; int co1;
-    int B; int H; int W;
-    int pad_mode; int act;
-    int tiles_per_img; int plane;
-};
+#include "conv_args.h"
 
 // One wave per SIMD with the whole 512-register budget (__launch_bounds__(256, 1)):
 // CT*PT accumulator tiles (256 VGPRs at 4x4) plus the prefetch registers of the
@@ -434,6 +422,7 @@ extern "C" int scm_conv3x3(const scm_conv3x3_desc* d, void* stream) {
     k.y1 = d->y1; k.y2 = d->y2; k.co1 = d->co1;
     k.B = d->B; k.H = d->H; k.W = d->W; k.pad_mode = d->pad_mode; k.act = d->act;
     k.tiles_per_img = 0; k.plane = 0;
+    if (d->cout <= 16) return scm_launch_conv3x3_m16(k, (hipStream_t)stream);
     const int ct = conv_ct(d->cout);
     const int groups = (d->cout + ct * 32 - 1) / (ct * 32);
     hipStream_t s = (hipStream_t)stream;

@@ -1,0 +1,21 @@
+// Kernel-argument block shared by the 3x3 MFMA conv kernels (conv3x3_mfma.hip, conv3x3_m16.hip).
+#pragma once
+#include "common.h"
+
+#define KC 8
+#define MAXJ 8
+
+struct ConvKArgs {
+    const float* x1; const float* x2; int c1; int c2;
+    const float* gate1; const float* gate2; int gate_act;
+    const float* wpack; int cout;
+    const float* scale; const float* bias; const float* sbias;
+    float* y1; float* y2; int co1;
+    int B; int H; int W;
+    int pad_mode; int act;
+    int tiles_per_img; int plane;
+};
+
+
+// cout <= 16 variant on v_mfma_f32_16x16x4_f32 (conv3x3_m16.hip)
+int scm_launch_conv3x3_m16(const ConvKArgs& k, hipStream_t s);
