@@ -267,6 +267,184 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN) / 4) conv3x3_wgrad_ker
     }
 }
 
+// ---------------------------------------------------------------- cout <= 16
+// Same algorithm on v_mfma_f32_16x16x4_f32 for the 16-channel-latent layers
+// (Transition.conv6, Encoder.conv4, the Decoder's factor-summed conv2): a 32-row
+// tile would be half (or 29/32) padding.  A = dyp[co (lane&15)][4 pixels (lane>>4)],
+// B = x[4 pixels][ci (lane&15)]; 8 waves (two per SIMD), wave w owns ci tile w of the
+// workgroup's 128 input channels and its 9 tap accumulators (36 registers).
+__global__ void __launch_bounds__(512, 2) conv3x3_wgrad_m16_kernel(const WgradKArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NW = 8, NCI = 128, XR = NCI / NW, DR = 16 / NW;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int W = a.W, H = a.H, HW = H * W;
+    const int PS = a.PS;
+    const int PSP = PS + 6;                 // cols -1 .. pse+1 with pse <= PS+3
+    const int XPL = (3 * PSP) | 1;
+    const int DPL = (PS + 4) | 1;
+    float* xl = smem;                  // [128][XPL]
+    float* dyl = smem + NCI * XPL;     // [16][DPL]
+
+    const int split = blockIdx.x;
+    const int b = split / a.spi;
+    const int si = split - b * a.spi;
+    const int y_begin = si * a.rows_per_split;
+    int y_end = y_begin + a.rows_per_split;
+    if (y_end > H) y_end = H;
+    const int cig = blockIdx.y;
+    const int ci_base = cig * NCI;
+    const int cin = a.c1 + a.c2;
+    const bool circ = a.pad_mode == SCM_PAD_CIRCULAR;
+    const int gate_act = a.gate_act;
+
+    f32x4 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float csum = 0.f;
+    const bool do_csum = a.csum_part != nullptr && cig == 0 && wave == 0;
+    const bool live = ci_base + wave * 16 < cin;
+
+    const float* ap = dyl + l15 * DPL + lq;
+    const float* bp = xl + (wave * 16 + l15) * XPL + lq;
+
+    auto xbase = [&](int c, bool& valid) -> const float* {
+        const int ci = ci_base + c;
+        valid = ci < cin;
+        const int cc = valid ? ci : 0;
+        return cc < a.c1 ? a.x1 + ((size_t)b * a.c1 + cc) * HW : a.x2 + ((size_t)b * a.c2 + (cc - a.c1)) * HW;
+    };
+    const int hc = tid >> 1, hs = tid & 1;       // halo element of this thread (threads 0..255)
+    bool hvalid = false;
+    const float* hsrc = xbase(hc < NCI ? hc : 0, hvalid);
+    hvalid = hvalid && hc < NCI;
+
+    float pdy[DR], pg[DR], px[XR], phalo = 0.f;
+
+    for (int seg = 0; seg < a.nseg; ++seg) {
+        const int x0 = seg * PS;
+        int ps = W - x0;
+        if (ps > PS) ps = PS;
+        const int pse = (ps + 3) & ~3;           // k-steps of 4 pixels
+        auto img_col = [&](int cc, bool& ok) -> int {
+            int xi = x0 + cc - 1;
+            if (circ) {
+                ok = true;
+                xi = xi < 0 ? xi + W : (xi >= W ? xi - W : xi);
+            } else {
+                ok = (xi >= 0 && xi < W);
+            }
+            return xi < 0 ? 0 : (xi >= W ? W - 1 : xi);
+        };
+        bool ok_main, ok_halo;
+        const int xi_main = img_col(lane + 1, ok_main);
+        ok_main = ok_main && (lane < pse + 1);
+        const int hcc = hs ? pse + 1 : 0;
+        const int xi_halo = img_col(hcc, ok_halo);
+        ok_halo = ok_halo && hvalid;
+        const int lane_c = lane < ps ? lane : ps - 1;
+
+        auto fetch_xrow = [&](int r) {
+            int ri = r;
+            if (circ) ri = r < 0 ? r + H : (r >= H ? r - H : r);
+            ri = ri < 0 ? 0 : (ri >= H ? H - 1 : ri);
+            const int ro = ri * W;
+#pragma unroll
+            for (int k = 0; k < XR; ++k) {
+                bool cv;
+                const float* src = xbase(wave * XR + k, cv);
+                px[k] = src[ro + xi_main];
+            }
+            phalo = hsrc[ro + xi_halo];
+        };
+        auto store_xrow = [&](int r) {
+            const int slot = (r + 3) % 3;
+            const bool rvalid = circ || (r >= 0 && r < H);
+            if (lane < pse + 1) {
+#pragma unroll
+                for (int k = 0; k < XR; ++k) {
+                    const bool cv = ci_base + wave * XR + k < cin;
+                    xl[(wave * XR + k) * XPL + slot * PSP + lane + 1] = (cv && rvalid && ok_main) ? px[k] : 0.f;
+                }
+            }
+            if (hc < NCI) xl[hc * XPL + slot * PSP + hcc] = (rvalid && ok_halo) ? phalo : 0.f;
+        };
+        auto fetch_dy = [&](int y) {
+#pragma unroll
+            for (int k = 0; k < DR; ++k) {
+                const int co = wave * DR + k;
+                const int coc = co < a.cout ? co : a.cout - 1;
+                const size_t rowo = ((size_t)b * a.cout + coc) * HW + (size_t)y * W + x0;
+                pdy[k] = a.dy[rowo + lane_c];
+                pg[k] = gate_act ? a.gate[rowo + lane_c] : 1.f;
+            }
+        };
+        auto store_dy = [&]() {
+            if (lane < pse) {
+#pragma unroll
+                for (int k = 0; k < DR; ++k) {
+                    const bool ok = wave * DR + k < a.cout && lane < ps;
+                    const float v = gate_act ? pdy[k] * scm_act_grad_from_out(pg[k], gate_act) : pdy[k];
+                    dyl[(wave * DR + k) * DPL + lane] = ok ? v : 0.f;
+                }
+            }
+        };
+
+        __syncthreads();
+        fetch_xrow(y_begin - 1);
+        store_xrow(y_begin - 1);
+        fetch_xrow(y_begin);
+        store_xrow(y_begin);
+        fetch_xrow(y_begin + 1);
+        fetch_dy(y_begin);
+
+        for (int y = y_begin; y < y_end; ++y) {
+            __syncthreads();
+            store_xrow(y + 1);
+            store_dy();
+            __syncthreads();
+            if (y + 1 < y_end) {
+                fetch_xrow(y + 2);
+                fetch_dy(y + 1);
+            }
+            const int ro0 = ((y + 2) % 3) * PSP, ro1 = (y % 3) * PSP, ro2 = ((y + 1) % 3) * PSP;
+            const int nks = pse >> 2;
+            if (live || do_csum) {
+#pragma unroll 2
+                for (int ks = 0; ks < nks; ++ks) {
+                    const float av = ap[4 * ks];
+                    if (do_csum) csum += av;
+                    const float* q = bp + 4 * ks;
+                    float bv[9];
+                    bv[0] = q[ro0]; bv[1] = q[ro0 + 1]; bv[2] = q[ro0 + 2];
+                    bv[3] = q[ro1]; bv[4] = q[ro1 + 1]; bv[5] = q[ro1 + 2];
+                    bv[6] = q[ro2]; bv[7] = q[ro2 + 1]; bv[8] = q[ro2 + 2];
+#pragma unroll
+                    for (int t = 0; t < 9; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[t], acc[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    const int ci = ci_base + wave * 16 + l15;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = 4 * lq + r;
+            if (co < a.cout && ci < cin) a.part[(((size_t)split * 9 + t) * a.cout + co) * cin + ci] = acc[t][r];
+        }
+    }
+    if (do_csum) {
+        csum += __shfl_xor(csum, 16);
+        csum += __shfl_xor(csum, 32);
+        if (lq == 0 && l15 < a.cout) a.csum_part[(size_t)split * a.cout + l15] = csum;
+    }
+}
+
 // Sum the per-split slabs in split order and scatter into the torch layout.
 //   dw[co][ci][3][3]                    (transposed_dst == 0, nn.Conv2d)
 //   dw[ci][co][3][3] with taps flipped  (transposed_dst == 1, nn.ConvTranspose2d)
@@ -335,16 +513,18 @@ __global__ void __launch_bounds__(1024) csum_reduce_kernel(const float* __restri
 
 // ------------------------------------------------------------------ host
 struct WgradPlan {
-    int mt, nt, spi, rows_per_split, nseg, PS, co_groups, ci_groups, nsplit;
+    int mt, nt, spi, rows_per_split, nseg, PS, co_groups, ci_groups, nsplit, m16;
 };
 
 static int wgrad_plan(int B, int H, int W, int cin, int cout, WgradPlan* p) {
     const int cot = (cout + 31) / 32, cit = (cin + 31) / 32;
+    p->m16 = cout <= 16 ? 1 : 0;
     if (cot >= 3) { p->mt = 4; p->nt = cit >= 2 ? 2 : 1; }     // 128 co x 64 (32) ci per workgroup
     else if (cot == 2) { p->mt = 2; p->nt = cit >= 3 ? 4 : 2; } //  64 co x 128 (64) ci
     else { p->mt = 1; p->nt = 4; }                             //  32 co x 128 ci
     p->co_groups = (cot + p->mt - 1) / p->mt;
     p->ci_groups = (cit + p->nt - 1) / p->nt;
+    if (p->m16) { p->co_groups = 1; p->ci_groups = (cin + 127) / 128; }
     p->nseg = (W + 63) / 64;
     p->PS = (W + p->nseg - 1) / p->nseg;
     const int groups = p->co_groups * p->ci_groups;
@@ -411,7 +591,21 @@ extern "C" int scm_conv3x3_wgrad(const scm_conv3x3_wgrad_desc* d, void* stream) 
     a.ci_groups = p.ci_groups;
     hipStream_t s = (hipStream_t)stream;
     int rc;
-    if (p.mt == 4) rc = p.nt == 2 ? launch_wgrad<4, 2, 1>(a, p, s) : launch_wgrad<4, 1, 1>(a, p, s);
+    if (p.m16) {
+        const int PSP = a.PS + 6, XPL = (3 * PSP) | 1, DPL = (a.PS + 4) | 1;
+        const size_t lds = ((size_t)128 * XPL + (size_t)16 * DPL) * sizeof(float);
+        static bool attr_set = false;
+        if (!attr_set) {
+            rc = scm_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_m16_kernel),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+                               "hipFuncSetAttribute");
+            if (rc) return rc;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(conv3x3_wgrad_m16_kernel, dim3(p.nsplit, p.ci_groups), dim3(512), lds, s, a);
+        SCM_LAUNCH_CHECK("conv3x3_wgrad_m16_kernel");
+        rc = SCM_OK;
+    } else if (p.mt == 4) rc = p.nt == 2 ? launch_wgrad<4, 2, 1>(a, p, s) : launch_wgrad<4, 1, 1>(a, p, s);
     else if (p.mt == 2) rc = p.nt == 4 ? launch_wgrad<2, 4, 1>(a, p, s) : launch_wgrad<2, 2, 1>(a, p, s);
     else rc = launch_wgrad<1, 4, 1>(a, p, s);
     if (rc) return rc;
