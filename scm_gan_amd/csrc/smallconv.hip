@@ -18,7 +18,9 @@ struct SmallConvArgs {
     int B, cin, H, W, cout, OH, OW, K, stride, pad, act;
 };
 
+template <int KT>
 __global__ void __launch_bounds__(256) smallconv_fwd_kernel(const SmallConvArgs a) {
+    const int K = KT ? KT : a.K;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     const int co0 = blockIdx.y * CB;
     const int b = blockIdx.z;
@@ -27,20 +29,26 @@ __global__ void __launch_bounds__(256) smallconv_fwd_kernel(const SmallConvArgs 
     float acc[CB];
 #pragma unroll
     for (int k = 0; k < CB; ++k) acc[k] = 0.f;
-    const int KK = a.K * a.K;
+    const int KK = K * K;
     for (int ci = 0; ci < a.cin; ++ci) {
         const float* xp = a.x + ((size_t)b * a.cin + ci) * a.H * a.W;
-        for (int ky = 0; ky < a.K; ++ky) {
+        // all K*K loads of this input plane are issued unconditionally (clamped, masked) so
+        // they fly together instead of one dependent load per tap
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
             const int iy = oy * a.stride - a.pad + ky;
-            if (iy < 0 || iy >= a.H) continue;
-            for (int kx = 0; kx < a.K; ++kx) {
+            const int iyc = iy < 0 ? 0 : (iy >= a.H ? a.H - 1 : iy);
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
                 const int ix = ox * a.stride - a.pad + kx;
-                if (ix < 0 || ix >= a.W) continue;
-                const float xv = xp[iy * a.W + ix];
+                const int ixc = ix < 0 ? 0 : (ix >= a.W ? a.W - 1 : ix);
+                const bool ok = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+                const float xr = xp[iyc * a.W + ixc];
+                const float xv = ok ? xr : 0.f;
 #pragma unroll
                 for (int k = 0; k < CB; ++k) {
-                    const int co = co0 + k;
-                    if (co < a.cout) acc[k] = fmaf(a.w[((size_t)co * a.cin + ci) * KK + ky * a.K + kx], xv, acc[k]);
+                    const int co = co0 + k < a.cout ? co0 + k : a.cout - 1;
+                    acc[k] = fmaf(a.w[((size_t)co * a.cin + ci) * KK + ky * K + kx], xv, acc[k]);
                 }
             }
         }
@@ -57,8 +65,10 @@ __global__ void __launch_bounds__(256) smallconv_fwd_kernel(const SmallConvArgs 
 }
 
 // dx[b,ci,iy,ix] = scale * sum_{co,ky,kx} dyp[b,co,oy,ox] w[co,ci,ky,kx], oy*stride-pad+ky == iy
+template <int KT>
 __global__ void __launch_bounds__(256) smallconv_dgrad_kernel(const SmallConvArgs a, const float* __restrict__ dy,
                                                               float* __restrict__ dx) {
+    const int K = KT ? KT : a.K;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     const int ci0 = blockIdx.y * CB;
     const int b = blockIdx.z;
@@ -67,25 +77,31 @@ __global__ void __launch_bounds__(256) smallconv_dgrad_kernel(const SmallConvArg
     float acc[CB];
 #pragma unroll
     for (int k = 0; k < CB; ++k) acc[k] = 0.f;
-    const int KK = a.K * a.K;
-    for (int ky = 0; ky < a.K; ++ky) {
-        const int ty = iy + a.pad - ky;
-        if (ty < 0 || ty % a.stride) continue;
-        const int oy = ty / a.stride;
-        if (oy >= a.OH) continue;
-        for (int kx = 0; kx < a.K; ++kx) {
-            const int tx = ix + a.pad - kx;
-            if (tx < 0 || tx % a.stride) continue;
-            const int ox = tx / a.stride;
-            if (ox >= a.OW) continue;
-            for (int co = 0; co < a.cout; ++co) {
-                const size_t o = ((size_t)b * a.cout + co) * a.OH * a.OW + oy * a.OW + ox;
+    const int KK = K * K;
+    const int OHW = a.OH * a.OW;
+    for (int co = 0; co < a.cout; ++co) {
+        const size_t ob = ((size_t)b * a.cout + co) * OHW;
+        // unconditional clamped loads of the (at most K*K) output pixels that read this input pixel
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+            const int ty = iy + a.pad - ky;
+            const int oy = ty / a.stride;
+            const bool oky = ty >= 0 && ty - oy * a.stride == 0 && oy < a.OH;
+            const int oyc = oy < 0 ? 0 : (oy >= a.OH ? a.OH - 1 : oy);
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+                const int tx = ix + a.pad - kx;
+                const int ox = tx / a.stride;
+                const bool ok = oky && tx >= 0 && tx - ox * a.stride == 0 && ox < a.OW;
+                const int oxc = ox < 0 ? 0 : (ox >= a.OW ? a.OW - 1 : ox);
+                const size_t o = ob + oyc * a.OW + oxc;
                 float g = dy[o];
                 if (a.gate_act) g *= scm_act_grad_from_out(a.gate[o], a.gate_act);
+                g = ok ? g : 0.f;
 #pragma unroll
                 for (int k = 0; k < CB; ++k) {
-                    const int ci = ci0 + k;
-                    if (ci < a.cin) acc[k] = fmaf(a.w[((size_t)co * a.cin + ci) * KK + ky * a.K + kx], g, acc[k]);
+                    const int ci = ci0 + k < a.cin ? ci0 + k : a.cin - 1;
+                    acc[k] = fmaf(a.w[((size_t)co * a.cin + ci) * KK + ky * K + kx], g, acc[k]);
                 }
             }
         }
@@ -102,12 +118,14 @@ __global__ void __launch_bounds__(256) smallconv_dgrad_kernel(const SmallConvArg
 // Two deterministic phases: workgroup (co, ci, split) reduces its slice of the batch
 // into ws[split][co][ci][k] (+ ws_db[split][co]); a second kernel sums the splits.
 #define SW_MAXKK 25
+template <int KT>
 __global__ void __launch_bounds__(256) smallconv_wgrad_kernel(const SmallConvArgs a, const float* __restrict__ dy,
                                                               float* __restrict__ ws, float* __restrict__ ws_db,
                                                               int bps) {
     __shared__ float red[4];
     const int co = blockIdx.x, ci = blockIdx.y, sp = blockIdx.z;
-    const int KK = a.K * a.K;
+    const int K = KT ? KT : a.K;
+    const int KK = K * K;
     float acc[SW_MAXKK];
 #pragma unroll
     for (int k = 0; k < SW_MAXKK; ++k) acc[k] = 0.f;
@@ -128,7 +146,7 @@ __global__ void __launch_bounds__(256) smallconv_wgrad_kernel(const SmallConvArg
 #pragma unroll
             for (int k = 0; k < SW_MAXKK; ++k) {
                 if (k < KK) {
-                    const int ky = k / a.K, kx = k - ky * a.K;
+                    const int ky = k / K, kx = k - ky * K;
                     const int iy = iy0 + ky, ix = ix0 + kx;
                     const bool ok = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
                     const int iyc = iy < 0 ? 0 : (iy >= a.H ? a.H - 1 : iy);
@@ -209,7 +227,8 @@ extern "C" int scm_conv2d_fwd(const scm_conv2d_desc* d, void* stream) {
     if (rc) return rc;
     SCM_REQUIRE(d->x && d->w && d->y, "scm_conv2d_fwd: x, w, y required");
     dim3 grid((a.OH * a.OW + 255) / 256, (a.cout + CB - 1) / CB, a.B);
-    hipLaunchKernelGGL(smallconv_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    if (a.K == 3) hipLaunchKernelGGL(smallconv_fwd_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(smallconv_fwd_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, a);
     SCM_LAUNCH_CHECK("smallconv_fwd_kernel");
     return SCM_OK;
 }
@@ -223,7 +242,8 @@ extern "C" int scm_conv2d_bwd(const scm_conv2d_desc* d, const float* dy, float* 
     SCM_REQUIRE(!d->gate_act || d->gate, "scm_conv2d_bwd: gate tensor required");
     if (dx) {
         dim3 grid((a.H * a.W + 255) / 256, (a.cin + CB - 1) / CB, a.B);
-        hipLaunchKernelGGL(smallconv_dgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, a, dy, dx);
+        if (a.K == 3) hipLaunchKernelGGL(smallconv_dgrad_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, a, dy, dx);
+        else hipLaunchKernelGGL(smallconv_dgrad_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, a, dy, dx);
         SCM_LAUNCH_CHECK("smallconv_dgrad_kernel");
     }
     if (dw) {
@@ -233,8 +253,12 @@ extern "C" int scm_conv2d_bwd(const scm_conv2d_desc* d, const float* dy, float* 
         const int nw = a.cout * a.cin * a.K * a.K;
         float* ws_db = ws + (size_t)ns * nw;
         dim3 grid(a.cout, a.cin, ns);
-        hipLaunchKernelGGL(smallconv_wgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, a, dy, ws,
-                           db ? ws_db : nullptr, bps);
+        if (a.K == 3)
+            hipLaunchKernelGGL(smallconv_wgrad_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, a, dy, ws,
+                               db ? ws_db : nullptr, bps);
+        else
+            hipLaunchKernelGGL(smallconv_wgrad_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, a, dy, ws,
+                               db ? ws_db : nullptr, bps);
         SCM_LAUNCH_CHECK("smallconv_wgrad_kernel");
         hipLaunchKernelGGL(smallconv_wgrad_reduce_kernel, dim3((nw + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws,
                            ws_db, ns, nw, a.cout, accumulate, dw, db);
