@@ -157,7 +157,8 @@ int scm_sn_fold_grad(const float* g, const float* w_bar, const float* u, const f
  * dot product is computed here by one workgroup. */
 
 /* ------------------------------------------------------------------------
- * Generic small Conv2d (square kernel K, stride, zero padding `pad`), direct
+ * Generic small Conv2d (square kernel K, stride, zero padding `pad`; a negative pad
+ * crops: RewardPredictor.conv2 reads the interior of conv1's same-size map with pad = -1), direct
  * form on the vector ALU: RewardPredictor (models.py:230-239), Discriminator
  * (models.py:199-219), CoordConv2d's inner conv (coordconv.py:8,15).
  *   fwd:  y = act( conv(x, w) * (*scale) + bias )
@@ -222,6 +223,16 @@ int scm_linear(const float* x, const float* w, const float* bias, int B, int nin
                void* stream);
 int scm_linear_bwd(const float* x, const float* w, const float* y, const float* gy, int B, int nin, int nout, int act,
                    float* dx, float* dw, float* db, void* stream);
+
+/* Loss bookkeeping of one unrolled step (main.py:178-197): mask_out = mask_in * (1 - done);
+ * loss_out = loss_in + coef * rd + rec, rd_rec = { rd, rec } with rd = mean_b(mean_r((rhat-r)^2) * mask_out),
+ * rec = mean_b(bce * mask_out); r / done are columns of (B,T,R) / (B,T) tensors (element strides
+ * given; loss_in may be NULL).  _bwd: gradients w.r.t. rhat and bce for upstream scalar g. */
+int scm_step_loss(const float* rhat, const float* r, long r_stride, const float* done, long done_stride,
+                  const float* bce, const float* mask_in, const float* loss_in, int B, int R, float coef,
+                  float* mask_out, float* loss_out, float* rd_rec, void* stream);
+int scm_step_loss_bwd(const float* rhat, const float* r, long r_stride, const float* mask, const float* g, int B,
+                      int R, float coef, float* d_rhat, float* d_bce, void* stream);
 
 /* CoordConv2d input: out[B][C+2][H][W] = cat(x, coord_x, coord_y) (coordconv.py:12-14). */
 int scm_coord_cat(const float* x, float* out, int B, int C, int H, int W, void* stream);

@@ -386,3 +386,68 @@ extern "C" int scm_coord_cat(const float* x, float* out, int B, int C, int H, in
     SCM_LAUNCH_CHECK("coord_cat_kernel");
     return SCM_OK;
 }
+
+// ------------------------------------------------------------ per-step loss
+// The loss bookkeeping of one unrolled step, main.py:178-197, in one launch:
+//   mask_out[b] = mask_in[b] * (1 - done[b])
+//   rd   = mean_b( mean_r((rhat - r)^2) * mask_out )          ("Rd Loss t=..")
+//   rec  = mean_b( bce[b] * mask_out )                        ("Reconstruction t=..")
+//   loss_out = loss_in + coef * rd + rec                      (coef = theta * REWARD_COEF)
+// r and done are column t of (B, T, R) / (B, T) tensors: element strides are passed.
+__global__ void __launch_bounds__(256) step_loss_kernel(const float* __restrict__ rhat, const float* __restrict__ r,
+                                                        long r_stride, const float* __restrict__ done,
+                                                        long done_stride, const float* __restrict__ bce,
+                                                        const float* __restrict__ mask_in, const float* loss_in,
+                                                        int B, int R, float coef, float* __restrict__ mask_out,
+                                                        float* __restrict__ loss_out, float* __restrict__ rd_rec) {
+    __shared__ float red[4];
+    float srd = 0.f, srec = 0.f;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        const float m = mask_in[b] * (1.f - done[(size_t)b * done_stride]);
+        mask_out[b] = m;
+        float s = 0.f;
+        for (int k = 0; k < R; ++k) {
+            const float d = rhat[(size_t)b * R + k] - r[(size_t)b * r_stride + k];
+            s = fmaf(d, d, s);
+        }
+        srd += s / (float)R * m;
+        srec += bce[b] * m;
+    }
+    srd = block_sum_256(srd, red);
+    srec = block_sum_256(srec, red);
+    if (threadIdx.x == 0) {
+        const float rd = srd / (float)B, rec = srec / (float)B;
+        loss_out[0] = (loss_in ? *loss_in : 0.f) + coef * rd + rec;
+        rd_rec[0] = rd;
+        rd_rec[1] = rec;
+    }
+}
+// d rhat[b][k] = g * coef * 2 (rhat - r) / (R B) * mask;  d bce[b] = g * mask / B
+__global__ void step_loss_bwd_kernel(const float* __restrict__ rhat, const float* __restrict__ r, long r_stride,
+                                     const float* __restrict__ mask, const float* __restrict__ g, int B, int R,
+                                     float coef, float* __restrict__ d_rhat, float* __restrict__ d_bce) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * R) return;
+    const int b = idx / R, k = idx - b * R;
+    const float gg = *g, m = mask[b];
+    d_rhat[idx] = gg * coef * 2.f * (rhat[idx] - r[(size_t)b * r_stride + k]) / (float)(R * B) * m;
+    if (k == 0) d_bce[b] = gg * m / (float)B;
+}
+extern "C" int scm_step_loss(const float* rhat, const float* r, long r_stride, const float* done, long done_stride,
+                             const float* bce, const float* mask_in, const float* loss_in, int B, int R, float coef,
+                             float* mask_out, float* loss_out, float* rd_rec, void* stream) {
+    SCM_REQUIRE(rhat && r && done && bce && mask_in && mask_out && loss_out && rd_rec && B > 0 && R > 0,
+                "scm_step_loss: bad arguments");
+    hipLaunchKernelGGL(step_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, rhat, r, r_stride, done,
+                       done_stride, bce, mask_in, loss_in, B, R, coef, mask_out, loss_out, rd_rec);
+    SCM_LAUNCH_CHECK("step_loss_kernel");
+    return SCM_OK;
+}
+extern "C" int scm_step_loss_bwd(const float* rhat, const float* r, long r_stride, const float* mask, const float* g,
+                                 int B, int R, float coef, float* d_rhat, float* d_bce, void* stream) {
+    SCM_REQUIRE(rhat && r && mask && g && d_rhat && d_bce && B > 0 && R > 0, "scm_step_loss_bwd: bad arguments");
+    hipLaunchKernelGGL(step_loss_bwd_kernel, dim3((B * R + 255) / 256), dim3(256), 0, (hipStream_t)stream, rhat, r,
+                       r_stride, mask, g, B, R, coef, d_rhat, d_bce);
+    SCM_LAUNCH_CHECK("step_loss_bwd_kernel");
+    return SCM_OK;
+}

@@ -210,7 +210,7 @@ extern "C" size_t scm_conv2d_bwd_workspace(int B, int cin, int cout, int K) {
 static int fill_args(const scm_conv2d_desc* d, SmallConvArgs* a, const char* who) {
     SCM_REQUIRE(d != nullptr, "%s: null descriptor", who);
     SCM_REQUIRE(d->B > 0 && d->cin > 0 && d->cout > 0 && d->H > 0 && d->W > 0, "%s: bad shape", who);
-    SCM_REQUIRE(d->K >= 1 && d->K * d->K <= SW_MAXKK && d->stride >= 1 && d->pad >= 0, "%s: bad K/stride/pad", who);
+    SCM_REQUIRE(d->K >= 1 && d->K * d->K <= SW_MAXKK && d->stride >= 1 && d->pad > -d->K, "%s: bad K/stride/pad", who);
     const int OH = (d->H + 2 * d->pad - d->K) / d->stride + 1, OW = (d->W + 2 * d->pad - d->K) / d->stride + 1;
     SCM_REQUIRE(OH > 0 && OW > 0, "%s: empty output", who);
     SCM_REQUIRE(d->act >= 0 && d->act <= 2 && d->gate_act >= 0 && d->gate_act <= 2, "%s: bad act", who);

@@ -80,6 +80,20 @@ class Conv2d(nn.Module):
             return full[:, :, 1:-1, 1:-1].contiguous()
         return ops.Conv2dFn.apply(x, w, self.bias, inv_sigma, u, v, self.kernel_size, self.stride, self.padding, act)
 
+    def forward_same(self, x, act=ops.ACT_NONE):
+        """The zero-padded SAME-size 3x3 conv of a padding-0 layer: its interior is this layer's
+        'valid' output (the caller reads the interior, e.g. through forward_cropped_input)."""
+        assert self.kernel_size == 3 and self.stride == 1 and self.padding == 0
+        cfg = {"pad": ops.PAD_ZERO, "act": act, "transposed": False, "packs": self._get_packs(self.weight, x.shape[1])}
+        return ops.Conv3x3Fn.apply(x, None, None, self.weight, self.bias, None, None, None, cfg)
+
+    def forward_cropped_input(self, x_full, crop, act=ops.ACT_NONE):
+        """This layer applied to x_full[:, :, crop:-crop, crop:-crop] without materialising the
+        crop: a padding of -crop on the direct kernel."""
+        assert not self.is_mfma
+        return ops.Conv2dFn.apply(x_full, self.weight, self.bias, None, None, None, self.kernel_size, self.stride,
+                                  self.padding - crop, act)
+
     def extra_repr(self):
         return "{in_channels}, {out_channels}, kernel_size={kernel_size}, stride={stride}, padding={padding}, " \
                "padding_mode={padding_mode}".format(**self.__dict__)

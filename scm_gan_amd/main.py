@@ -200,6 +200,7 @@ class Trainer(object):
 
         z = encoder(states[:, 0:3])                                            # main.py:162
         main_stream.wait_stream(self.side_stream)
+        targets = states.transpose(0, 1).contiguous()      # (T, B, C, H, W): targets[t] is one contiguous frame batch
         z_orig = z.clone() if (enable_cf_shuffle_loss or enable_control_bias_loss) else None
         active_mask = torch.ones(batch_size, device=states.device)
 
@@ -207,20 +208,16 @@ class Trainer(object):
         lo_loss = 0
         lo_z_set = {}
         for t in range(1, prediction_horizon - 1):                             # main.py:177
-            active_mask = active_mask * (1 - dones[:, t])
-
-            expected_reward = reward_predictor(z)
-            actual_reward = rewards[:, t]
-            reward_difference = torch.mean(torch.mean((expected_reward - actual_reward) ** 2, dim=1) * active_mask)
-            ts.collect('Rd Loss t={}'.format(t), reward_difference)
-            loss += theta * a.reward_coef * reward_difference                  # main.py:185
-
-            rec_loss_batch = decoder_pixel_loss(states[:, t], decoder(z))      # main.py:188-190
+            expected_reward = reward_predictor(z)                              # main.py:181
+            rec_loss_batch = decoder_pixel_loss(targets[t], decoder(z))        # main.py:188-190
             if a.truncate_bptt and t > 1:
                 z = z.detach()
-            rec_loss = torch.mean(rec_loss_batch * active_mask)
+            # main.py:178,182-185,195-197 in one launch: mask update, both masked means, loss accumulation
+            loss, reward_difference, rec_loss, active_mask = ops.StepLossFn.apply(
+                loss if torch.is_tensor(loss) else None, expected_reward, rec_loss_batch, rewards[:, t], dones[:, t],
+                active_mask, theta * a.reward_coef)
+            ts.collect('Rd Loss t={}'.format(t), reward_difference)
             ts.collect('Reconstruction t={}'.format(t), rec_loss)
-            loss += rec_loss                                                   # main.py:197
 
             z = transition(z, onehots[:, t])                                   # main.py:206-215
 
@@ -235,7 +232,7 @@ class Trainer(object):
 
         if a.latent_overshooting:
             ts.collect('LO total', lo_loss)
-            loss += theta * lo_loss
+            loss = loss + theta * lo_loss
 
         if enable_cf_shuffle_loss:
             # main.py:242-262; z_cf_b aliases z_orig and is mutated in place there
@@ -252,7 +249,7 @@ class Trainer(object):
                 z_cf_b = transition(z_cf_b, onehots[:, t])
             cf_loss = torch.abs(z_cf_a - z_cf_b).mean(-1).mean(-1) * unswapped_factor_map
             cf_loss = CF_REGULARIZATION_LAMBDA * torch.mean(cf_loss.mean(-1) * active_mask)
-            loss += cf_loss
+            loss = loss + cf_loss
             ts.collect('CF Disentanglement Loss', cf_loss)
 
         if enable_control_bias_loss:
@@ -267,7 +264,7 @@ class Trainer(object):
             eps = .001
             cf_loss = -torch.log(torch.abs(z_cf_a - z_cf_b).mean(-1).mean(-1).mean(-1) + eps)
             cf_loss = CF_REGULARIZATION_LAMBDA * torch.mean(cf_loss * active_mask)
-            loss += cf_loss
+            loss = loss + cf_loss
             ts.collect('CF Control Bias Loss', cf_loss)
 
         loss.backward()                                                        # main.py:285

@@ -134,8 +134,14 @@ class RewardPredictor(nn.Module):
         _to_gpu(self)
 
     def forward(self, x, visualize=False):
-        x = self.conv1(x, act=ops.ACT_LRELU)
-        x = self.conv2(x)
+        if x.shape[2] > 2 and x.shape[3] > 2:
+            # conv1 (valid 3x3) = interior of the same-size conv on the MFMA kernel; conv2 reads that
+            # interior in place (padding -1): no crop copy forward, no zero-embed backward
+            x = self.conv1.forward_same(x, act=ops.ACT_LRELU)
+            x = self.conv2.forward_cropped_input(x, 1)
+        else:
+            x = self.conv1(x, act=ops.ACT_LRELU)
+            x = self.conv2(x)
         r, rmap = ops.RewardTailFn.apply(x, self.num_rewards)
         if visualize:
             return r, rmap

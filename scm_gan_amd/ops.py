@@ -510,3 +510,38 @@ class CSRNSweepsFn(Function):
         for name in ("down", "up", "left", "right"):
             out += grads[name]
         return tuple(out)
+
+
+class StepLossFn(Function):
+    """Loss bookkeeping of one unrolled step (main.py:178-197) in one launch; returns
+    (loss_out, rd, rec, mask_out).  rewards_t / dones_t may be strided columns."""
+
+    @staticmethod
+    def forward(ctx, loss_in, rhat, bce, rewards_t, dones_t, mask_in, coef):
+        lib = L.lib()
+        rhat, bce, mask_in = _chk(rhat, "step_loss"), _chk(bce, "step_loss"), _chk(mask_in, "step_loss")
+        B, R = rhat.shape
+        assert rewards_t.stride(1) == 1 and rewards_t.is_cuda and dones_t.is_cuda
+        loss_out, rd_rec = _new(rhat, 1), _new(rhat, 2)
+        mask_out = _new(rhat, B)
+        lin = None if loss_in is None else _chk(loss_in, "step_loss")
+        L.check(lib.scm_step_loss(_p(rhat), ctypes.c_void_p(rewards_t.data_ptr()), rewards_t.stride(0),
+                                  ctypes.c_void_p(dones_t.data_ptr()), dones_t.stride(0), _p(bce), _p(mask_in),
+                                  _p(lin), B, R, coef, _p(mask_out), _p(loss_out), _p(rd_rec), _stream()), "scm_step_loss")
+        ctx.coef = coef
+        ctx.has_loss_in = loss_in is not None
+        ctx.save_for_backward(rhat, rewards_t, mask_out)
+        rd, rec = rd_rec[0:1], rd_rec[1:2]
+        ctx.mark_non_differentiable(mask_out, rd, rec)
+        return loss_out, rd, rec, mask_out
+
+    @staticmethod
+    def backward(ctx, g, g_rd, g_rec, g_mask):
+        rhat, rewards_t, mask = ctx.saved_tensors
+        B, R = rhat.shape
+        g = _chk(g, "step_loss.backward")
+        d_rhat, d_bce = torch.empty_like(rhat), _new(rhat, B)
+        L.check(L.lib().scm_step_loss_bwd(_p(rhat), ctypes.c_void_p(rewards_t.data_ptr()), rewards_t.stride(0),
+                                          _p(mask), _p(g), B, R, ctx.coef, _p(d_rhat), _p(d_bce), _stream()),
+                "scm_step_loss_bwd")
+        return (g if ctx.has_loss_in else None), d_rhat, d_bce, None, None, None, None
