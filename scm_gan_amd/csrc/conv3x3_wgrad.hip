@@ -54,10 +54,11 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN) / 4) conv3x3_wgrad_ker
     const int W = a.W, H = a.H, HW = H * W;
     const int PS = a.PS;
     const int PSP = PS + 4;                 // row pitch of the x tile (cols -1 .. PS+2)
-    const int XPL = (3 * PSP) | 1;          // odd plane pitch: conflict-free lane->ci reads
+    const int XPL = (4 * PSP) | 1;          // 4 rolling row slots; odd plane pitch: conflict-free lane->ci reads
     const int DPL = (PS + 2) | 1;           // odd row pitch of the dy tile: lane->co reads
     float* xl = smem;                       // [NT*32][XPL]
-    float* dyl = smem + NT * 32 * XPL;      // [MT*32][DPL]
+    float* dyl = smem + NT * 32 * XPL;      // [2][MT*32][DPL]  (double-buffered)
+    const int DYB = MT * 32 * DPL;
 
     const int split = blockIdx.x;
     const int b = split / a.spi;
@@ -150,7 +151,7 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN) / 4) conv3x3_wgrad_ker
             phalo = hsrc[ro + xi_halo];
         };
         auto store_xrow = [&](int r) {
-            const int slot = (r + 3) % 3;
+            const int slot = (r + 4) & 3;
             const bool rvalid = circ || (r >= 0 && r < H);
             if (lane < pse + 1) {
 #pragma unroll
@@ -172,42 +173,45 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN) / 4) conv3x3_wgrad_ker
                 pg[k] = gate_act ? a.gate[rowo + lane_c] : 1.f;
             }
         };
-        auto store_dy = [&]() {      // mask + act' multiply happen here, after the MFMAs that hid the loads
+        auto store_dy = [&](int buf) {      // mask + act' multiply happen here, after the MFMAs that hid the loads
+            float* dyb = dyl + buf * DYB;
             if (lane < pse) {
 #pragma unroll
                 for (int k = 0; k < DR; ++k) {
                     const bool ok = co_base + wave * DR + k < a.cout && lane < ps;
                     const float v = gate_act ? pdy[k] * scm_act_grad_from_out(pg[k], gate_act) : pdy[k];
-                    dyl[(wave * DR + k) * DPL + lane] = ok ? v : 0.f;
+                    dyb[(wave * DR + k) * DPL + lane] = ok ? v : 0.f;
                 }
             }
         };
 
-        // ---- prologue of the band: rows y_begin-1 and y_begin go straight to LDS
+        // ---- prologue of the band: rows y_begin-1 .. y_begin+1 and dy row y_begin go straight to LDS
         __syncthreads();
         fetch_xrow(y_begin - 1);
         store_xrow(y_begin - 1);
         fetch_xrow(y_begin);
         store_xrow(y_begin);
         fetch_xrow(y_begin + 1);
+        store_xrow(y_begin + 1);
         fetch_dy(y_begin);
+        store_dy(0);
+        if (y_begin + 1 < y_end) {
+            fetch_xrow(y_begin + 2);
+            fetch_dy(y_begin + 1);
+        }
+        __syncthreads();
 
+        // One barrier per image row: the dy tile is double-buffered and the x rows live in
+        // FOUR rolling slots, so row y+1's data (prefetched into registers a row ago) is
+        // written to LDS in the middle of row y's MFMAs, then row y+2's loads are issued.
         for (int y = y_begin; y < y_end; ++y) {
-            __syncthreads();                 // previous row's MFMAs are done with the tiles
-            store_xrow(y + 1);
-            store_dy();
-            __syncthreads();
-            if (y + 1 < y_end) {             // next row's loads fly under this row's MFMAs
-                fetch_xrow(y + 2);
-                fetch_dy(y + 1);
-            }
-            const int ro0 = ((y + 2) % 3) * PSP, ro1 = (y % 3) * PSP, ro2 = ((y + 1) % 3) * PSP;
+            const int cur = (y - y_begin) & 1;
+            const float* apc = ap + cur * DYB;
+            const int ro0 = ((y + 3) & 3) * PSP, ro1 = ((y + 4) & 3) * PSP, ro2 = ((y + 5) & 3) * PSP;
             const int nks = pse >> 1;
-            // explicit register double-buffer of the LDS operands: with one wave per SIMD
-            // nothing else hides the ds_read latency, so k-step s+1's reads are issued
-            // before k-step s's 9*NTW MFMAs.
+            const int nhalf = (nks / 2 + 1) & ~1;        // even split point (the k loop steps by 2)
             auto lds_k = [&](int ks, float& av, float (&bv)[NTW][9]) {
-                av = ap[2 * ks];
+                av = apc[2 * ks];
 #pragma unroll
                 for (int n = 0; n < NTW; ++n) {
                     const float* q = bp + n * 32 * XPL + 2 * ks;
@@ -228,21 +232,34 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN) / 4) conv3x3_wgrad_ker
                     }
                 }
             };
-            auto row_loop = [&](auto checked) {
+            // k-steps [k0, k1) with an explicit register double-buffer of the LDS operands
+            auto row_loop = [&](int k0, int k1, auto checked) {
+                if (k0 >= k1) return;
                 float av0, av1, bv0[NTW][9], bv1[NTW][9];
-                lds_k(0, av0, bv0);
+                lds_k(k0, av0, bv0);
 #pragma unroll 1
-                for (int ks = 0; ks < nks; ks += 2) {
-                    const int k1 = ks + 1 < nks ? ks + 1 : nks - 1;
-                    lds_k(k1, av1, bv1);
+                for (int ks = k0; ks < k1; ks += 2) {
+                    const int ka = ks + 1 < k1 ? ks + 1 : k1 - 1;
+                    lds_k(ka, av1, bv1);
                     mfma_k(av0, bv0, checked);
-                    const int k2 = ks + 2 < nks ? ks + 2 : nks - 1;
-                    lds_k(k2, av0, bv0);
-                    if (ks + 1 < nks) mfma_k(av1, bv1, checked);
+                    const int kb = ks + 2 < k1 ? ks + 2 : k1 - 1;
+                    lds_k(kb, av0, bv0);
+                    if (ks + 1 < k1) mfma_k(av1, bv1, checked);
                 }
             };
-            if (all_live) row_loop(std::false_type{});
-            else row_loop(std::true_type{});
+            if (all_live) row_loop(0, nhalf, std::false_type{});
+            else row_loop(0, nhalf, std::true_type{});
+            if (y + 1 < y_end) {             // row y+1's tiles -> the idle dy buffer and the free x slot
+                store_xrow(y + 2);
+                store_dy(cur ^ 1);
+            }
+            if (y + 2 < y_end) {             // row y+2's loads fly under the rest of this row and the next
+                fetch_xrow(y + 3);
+                fetch_dy(y + 2);
+            }
+            if (all_live) row_loop(nhalf, nks, std::false_type{});
+            else row_loop(nhalf, nks, std::true_type{});
+            __syncthreads();
         }
     }
 
@@ -551,8 +568,8 @@ extern "C" int scm_conv3x3_wgrad_workspace(int B, int H, int W, int cin, int cou
 template <int WM, int WN, int NTW>
 static int launch_wgrad(const WgradKArgs& a, const WgradPlan& p, hipStream_t s) {
     constexpr int MT = WM, NT = WN * NTW;
-    const int PSP = a.PS + 4, XPL = (3 * PSP) | 1, DPL = (a.PS + 2) | 1;
-    const size_t lds = ((size_t)NT * 32 * XPL + (size_t)MT * 32 * DPL) * sizeof(float);
+    const int PSP = a.PS + 4, XPL = (4 * PSP) | 1, DPL = (a.PS + 2) | 1;
+    const size_t lds = ((size_t)NT * 32 * XPL + (size_t)2 * MT * 32 * DPL) * sizeof(float);
     auto kern = conv3x3_wgrad_kernel<WM, WN, NTW>;
     static bool attr_set = false;
     if (!attr_set) {
