@@ -87,7 +87,9 @@ kernel_timer = None     # set to a KernelTimer() to time the MFMA conv launches
 
 
 def conv_kernel_name(cout):
-    return "conv3x3_mfma_kernel<%s>" % ("4,x" if cout > 64 else ("2,4" if cout > 32 else "1,8"))
+    if cout <= 16:
+        return "conv3x3_m16_kernel"
+    return "conv3x3_mfma_kernel<%s>" % ("4,2|4,4" if cout > 64 else ("2,4" if cout > 32 else "1,8"))
 
 
 def _conv3x3_raw(x1, x2, gate1, gate2, gate_act, wpack, cout, scale, bias, sbias, co1, pad, act):
