@@ -290,9 +290,11 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN) / 4) conv3x3_wgrad_ker
 // tile would be half (or 29/32) padding.  A = dyp[co (lane&15)][4 pixels (lane>>4)],
 // B = x[4 pixels][ci (lane&15)]; 8 waves (two per SIMD), wave w owns ci tile w of the
 // workgroup's 128 input channels and its 9 tap accumulators (36 registers).
+template <int NCO, int NCI>
 __global__ void __launch_bounds__(512, 2) conv3x3_wgrad_m16_kernel(const WgradKArgs a) {
+    static_assert(NCO * NCI == 8, "8 waves");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int NW = 8, NCI = 128, XR = NCI / NW, DR = 16 / NW;
+    constexpr int NW = 8, NCIC = NCI * 16, NCOC = NCO * 16, XR = NCIC / NW, DR = NCOC / NW;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -302,8 +304,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wgrad_m16_kernel(const WgradKA
     const int PSP = PS + 6;                 // cols -1 .. pse+1 with pse <= PS+3
     const int XPL = (3 * PSP) | 1;
     const int DPL = (PS + 4) | 1;
-    float* xl = smem;                  // [128][XPL]
-    float* dyl = smem + NCI * XPL;     // [16][DPL]
+    float* xl = smem;                  // [NCI*16][XPL]
+    float* dyl = smem + NCIC * XPL;    // [NCO*16][DPL]
 
     const int split = blockIdx.x;
     const int b = split / a.spi;
@@ -311,8 +313,10 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wgrad_m16_kernel(const WgradKA
     const int y_begin = si * a.rows_per_split;
     int y_end = y_begin + a.rows_per_split;
     if (y_end > H) y_end = H;
-    const int cig = blockIdx.y;
-    const int ci_base = cig * NCI;
+    const int cig = blockIdx.y % a.ci_groups;
+    const int cog = blockIdx.y / a.ci_groups;
+    const int ci_base = cig * NCIC, co_base = cog * NCOC;
+    const int wco = wave / NCI, wci = wave % NCI;
     const int cin = a.c1 + a.c2;
     const bool circ = a.pad_mode == SCM_PAD_CIRCULAR;
     const int gate_act = a.gate_act;
@@ -321,11 +325,11 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wgrad_m16_kernel(const WgradKA
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     float csum = 0.f;
-    const bool do_csum = a.csum_part != nullptr && cig == 0 && wave == 0;
-    const bool live = ci_base + wave * 16 < cin;
+    const bool do_csum = a.csum_part != nullptr && cig == 0 && wci == 0 && co_base + wco * 16 < a.cout;
+    const bool live = ci_base + wci * 16 < cin && co_base + wco * 16 < a.cout;
 
-    const float* ap = dyl + l15 * DPL + lq;
-    const float* bp = xl + (wave * 16 + l15) * XPL + lq;
+    const float* ap = dyl + (wco * 16 + l15) * DPL + lq;
+    const float* bp = xl + (wci * 16 + l15) * XPL + lq;
 
     auto xbase = [&](int c, bool& valid) -> const float* {
         const int ci = ci_base + c;
@@ -335,8 +339,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wgrad_m16_kernel(const WgradKA
     };
     const int hc = tid >> 1, hs = tid & 1;       // halo element of this thread (threads 0..255)
     bool hvalid = false;
-    const float* hsrc = xbase(hc < NCI ? hc : 0, hvalid);
-    hvalid = hvalid && hc < NCI;
+    const float* hsrc = xbase(hc < NCIC ? hc : 0, hvalid);
+    hvalid = hvalid && hc < NCIC;
 
     float pdy[DR], pg[DR], px[XR], phalo = 0.f;
 
@@ -386,12 +390,12 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wgrad_m16_kernel(const WgradKA
                     xl[(wave * XR + k) * XPL + slot * PSP + lane + 1] = (cv && rvalid && ok_main) ? px[k] : 0.f;
                 }
             }
-            if (hc < NCI) xl[hc * XPL + slot * PSP + hcc] = (rvalid && ok_halo) ? phalo : 0.f;
+            if (hc < NCIC) xl[hc * XPL + slot * PSP + hcc] = (rvalid && ok_halo) ? phalo : 0.f;
         };
         auto fetch_dy = [&](int y) {
 #pragma unroll
             for (int k = 0; k < DR; ++k) {
-                const int co = wave * DR + k;
+                const int co = co_base + wave * DR + k;
                 const int coc = co < a.cout ? co : a.cout - 1;
                 const size_t rowo = ((size_t)b * a.cout + coc) * HW + (size_t)y * W + x0;
                 pdy[k] = a.dy[rowo + lane_c];
@@ -402,7 +406,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wgrad_m16_kernel(const WgradKA
             if (lane < pse) {
 #pragma unroll
                 for (int k = 0; k < DR; ++k) {
-                    const bool ok = wave * DR + k < a.cout && lane < ps;
+                    const bool ok = co_base + wave * DR + k < a.cout && lane < ps;
                     const float v = gate_act ? pdy[k] * scm_act_grad_from_out(pg[k], gate_act) : pdy[k];
                     dyl[(wave * DR + k) * DPL + lane] = ok ? v : 0.f;
                 }
@@ -446,19 +450,20 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wgrad_m16_kernel(const WgradKA
         }
     }
 
-    const int ci = ci_base + wave * 16 + l15;
+    const int ci = ci_base + wci * 16 + l15;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int co = 4 * lq + r;
+            const int co = co_base + wco * 16 + 4 * lq + r;
             if (co < a.cout && ci < cin) a.part[(((size_t)split * 9 + t) * a.cout + co) * cin + ci] = acc[t][r];
         }
     }
     if (do_csum) {
         csum += __shfl_xor(csum, 16);
         csum += __shfl_xor(csum, 32);
-        if (lq == 0 && l15 < a.cout) a.csum_part[(size_t)split * a.cout + l15] = csum;
+        const int co = co_base + wco * 16 + l15;
+        if (lq == 0 && co < a.cout) a.csum_part[(size_t)split * a.cout + co] = csum;
     }
 }
 
@@ -535,13 +540,14 @@ struct WgradPlan {
 
 static int wgrad_plan(int B, int H, int W, int cin, int cout, WgradPlan* p) {
     const int cot = (cout + 31) / 32, cit = (cin + 31) / 32;
-    p->m16 = cout <= 16 ? 1 : 0;
+    p->m16 = cout <= 16 ? 1 : (cin <= 16 ? 2 : 0);     // 1: 16 co x 128 ci per WG; 2: 128 co x 16 ci per WG
     if (cot >= 3) { p->mt = 4; p->nt = cit >= 2 ? 2 : 1; }     // 128 co x 64 (32) ci per workgroup
     else if (cot == 2) { p->mt = 2; p->nt = cit >= 3 ? 4 : 2; } //  64 co x 128 (64) ci
     else { p->mt = 1; p->nt = 4; }                             //  32 co x 128 ci
     p->co_groups = (cot + p->mt - 1) / p->mt;
     p->ci_groups = (cit + p->nt - 1) / p->nt;
-    if (p->m16) { p->co_groups = 1; p->ci_groups = (cin + 127) / 128; }
+    if (p->m16 == 1) { p->co_groups = 1; p->ci_groups = (cin + 127) / 128; }
+    if (p->m16 == 2) { p->co_groups = (cout + 127) / 128; p->ci_groups = 1; }
     p->nseg = (W + 63) / 64;
     p->PS = (W + p->nseg - 1) / p->nseg;
     const int groups = p->co_groups * p->ci_groups;
@@ -609,17 +615,19 @@ extern "C" int scm_conv3x3_wgrad(const scm_conv3x3_wgrad_desc* d, void* stream) 
     hipStream_t s = (hipStream_t)stream;
     int rc;
     if (p.m16) {
+        const int nci = p.m16 == 1 ? 128 : 16, nco = p.m16 == 1 ? 16 : 128;
         const int PSP = a.PS + 6, XPL = (3 * PSP) | 1, DPL = (a.PS + 4) | 1;
-        const size_t lds = ((size_t)128 * XPL + (size_t)16 * DPL) * sizeof(float);
-        static bool attr_set = false;
-        if (!attr_set) {
-            rc = scm_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_m16_kernel),
+        const size_t lds = ((size_t)nci * XPL + (size_t)nco * DPL) * sizeof(float);
+        auto kern = p.m16 == 1 ? conv3x3_wgrad_m16_kernel<1, 8> : conv3x3_wgrad_m16_kernel<8, 1>;
+        static bool attr_set[2] = {false, false};
+        if (!attr_set[p.m16 - 1]) {
+            rc = scm_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
                                "hipFuncSetAttribute");
             if (rc) return rc;
-            attr_set = true;
+            attr_set[p.m16 - 1] = true;
         }
-        hipLaunchKernelGGL(conv3x3_wgrad_m16_kernel, dim3(p.nsplit, p.ci_groups), dim3(512), lds, s, a);
+        hipLaunchKernelGGL(kern, dim3(p.nsplit, p.co_groups * p.ci_groups), dim3(512), lds, s, a);
         SCM_LAUNCH_CHECK("conv3x3_wgrad_m16_kernel");
         rc = SCM_OK;
     } else if (p.mt == 4) rc = p.nt == 2 ? launch_wgrad<4, 2, 1>(a, p, s) : launch_wgrad<4, 1, 1>(a, p, s);
