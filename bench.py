@@ -25,14 +25,15 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 H = W = 64
-C, A, R, L = 3, 5, 2, 16
+C, A, R, L = 3, 5, 2, 16      # BASELINE configs[1]; --size/--channels/--actions/--rewards select the other shapes
 
 
 def algorithmic_gflop_per_frame(horizon):
-    """2*MAC, train = 3x forward, per predicted frame."""
+    """SURVEY.md section 8d: 2*MAC, train = 3x forward, per predicted frame (64x64, C=3, A=5, R=2;
+    scaled by the pixel count for other sizes -- the C/A/R dependence is < 1 %)."""
     enc = 2.652
     step = 6.540 + 0.302 + 0.0385
-    return 3.0 * (enc + (horizon - 2) * step) / (horizon - 2)
+    return 3.0 * (enc + (horizon - 2) * step) / (horizon - 2) * (H * W) / 4096.0
 
 
 def build_nets(seed):
@@ -144,9 +145,17 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (BASELINE configs[1])")
     ap.add_argument("--horizon", type=int, default=10)
+    ap.add_argument("--size", type=int, default=64, help="frame height = width (84: configs[3], 128: configs[4] shapes)")
+    ap.add_argument("--channels", type=int, default=3)
+    ap.add_argument("--actions", type=int, default=5)
+    ap.add_argument("--rewards", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     a = ap.parse_args()
+    global H, W, C, A, R
+    H = W = a.size
+    C, A, R = a.channels, a.actions, a.rewards
+    headline = (a.size, a.channels, a.actions, a.rewards, a.batch, a.horizon) == (64, 3, 5, 2, 64, 10)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -207,9 +216,10 @@ def main():
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: minipacman-shaped 64x64x3, per-GPU batch %d, horizon %d, A=5, R=2, "
+            "config": {"workload": "%s: %dx%dx%d frames, per-GPU batch %d, horizon %d, A=%d, R=%d, "
                                    "training iteration fwd+bwd+clip+Adam, reference loss (BCE + reward MSE), no "
-                                   "discriminator" % (a.batch, a.horizon),
+                                   "discriminator" % ("configs[1] minipacman-shaped" if headline else "non-headline shape",
+                                                      H, W, C, a.batch, a.horizon, A, R),
                        "global_batch": a.batch * world, "horizon": a.horizon, "parallelism": "dp%d" % world},
             "algorithmic_tflops": value * algorithmic_gflop_per_frame(a.horizon) / 1e3,
         }
@@ -231,7 +241,7 @@ def main():
                                "share_of_step": s["ms"] / (dt * 1e3)}
             out["kernels"] = {k: {"launches": v["launches"], "ms_total": round(v["ms"], 3),
                                   "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12} for k, v in summ.items()}
-        if world == 1:
+        if world == 1 and headline:
             l1, flips = rollout_l1(dev)
             out["rollout_l1_vs_ref"] = l1
             out["rollout_latent_flips"] = flips
