@@ -138,6 +138,35 @@ def rollout_l1(dev):
     return float(np.mean(l1)), flips
 
 
+def decoder_leg(dev, batch):
+    """Decoder forward + pixel loss in isolation (north star: achieved HBM GB/s on the decoder).
+    Algorithmic bytes per frame = read z (16 planes) + write C logit planes (SURVEY.md section 8d:
+    311 296 B at 64x64, C=3); the fused minimum.  The path is NOT HBM-bound: 970 FLOP per
+    algorithmic byte against a machine balance of ~20 FLOP/B, so the fp32 MFMA rate bounds it."""
+    from scm_gan_amd import models, ops
+    torch.manual_seed(0)
+    dec = models.Decoder(L, C)
+    z = (torch.rand(batch, L, H, W, device=dev) < 0.5).float()
+    target = (torch.rand(batch, C, H, W, device=dev) < 0.1).float()
+    with torch.no_grad():
+        for _ in range(3):
+            ops.pixel_bce(dec(z), target)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = 20
+        s.record()
+        for _ in range(n):
+            ops.pixel_bce(dec(z), target)
+        e.record()
+        torch.cuda.synchronize()
+    sec = s.elapsed_time(e) * 1e-3 / n
+    bytes_per_frame = (L + C) * H * W * 4
+    flops_per_frame = 2.0 * H * W * 9 * (L * 4 * L + 4 * L * L * C)
+    return {"frames_per_s": batch / sec, "us_per_launch_group": sec * 1e6,
+            "achieved_GBps_algorithmic": batch * bytes_per_frame / sec / 1e9, "peak_GBps": 8000.0,
+            "tflops_reference_formulation": batch * flops_per_frame / sec / 1e12,
+            "bound": "mfma (970 FLOP/B algorithmic intensity)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -241,6 +270,8 @@ def main():
                                "share_of_step": s["ms"] / (dt * 1e3)}
             out["kernels"] = {k: {"launches": v["launches"], "ms_total": round(v["ms"], 3),
                                   "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12} for k, v in summ.items()}
+        if world == 1:
+            out["decoder"] = decoder_leg(dev, a.batch)
         if world == 1 and headline:
             l1, flips = rollout_l1(dev)
             out["rollout_l1_vs_ref"] = l1
