@@ -112,15 +112,15 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 //           (torch.sigmoid + decoder_pixel_loss, main.py:189-190,310-312)
 //   kind 1: squared error (measure_prediction_mse, main.py:814-816)
 // prob (optional) receives sigmoid(logit).
-__global__ void __launch_bounds__(256) pixel_loss_kernel(const float* __restrict__ logit,
-                                                         const float* __restrict__ target, int n, int kind,
-                                                         float* __restrict__ per_sample, float* __restrict__ prob) {
-    __shared__ float red[4];
+__global__ void __launch_bounds__(1024) pixel_loss_kernel(const float* __restrict__ logit,
+                                                          const float* __restrict__ target, int n, int kind,
+                                                          float* __restrict__ per_sample, float* __restrict__ prob) {
+    __shared__ float red[16];
     const int b = blockIdx.x;
     const float* lp = logit + (size_t)b * n;
     const float* tp = target + (size_t)b * n;
     float s = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) {
+    for (int i = threadIdx.x; i < n; i += 1024) {
         const float p = 1.f / (1.f + expf(-lp[i]));
         const float t = tp[i];
         if (prob) prob[(size_t)b * n + i] = p;
@@ -132,8 +132,16 @@ __global__ void __launch_bounds__(256) pixel_loss_kernel(const float* __restrict
             s = fmaf(d, d, s);
         }
     }
-    s = block_sum_256(s, red);
-    if (threadIdx.x == 0) per_sample[b] = s / (float)n;
+    // 16 waves: wave sums meet in LDS, summed in a fixed order
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += red[w];
+        per_sample[b] = t / (float)n;
+    }
 }
 // dlogit = g[b]/n * dloss/dp * p(1-p); BCE: torch's binary_cross_entropy_backward
 // (p - t) / max((1-p) p, 1e-12); MSE: 2 (p - t)
@@ -152,7 +160,7 @@ __global__ void pixel_loss_bwd_kernel(const float* __restrict__ logit, const flo
 extern "C" int scm_pixel_loss(const float* logit, const float* target, int B, int n, int kind, float* per_sample,
                               float* prob, void* stream) {
     SCM_REQUIRE(logit && target && per_sample && B > 0 && n > 0 && (kind == 0 || kind == 1), "scm_pixel_loss: bad arguments");
-    hipLaunchKernelGGL(pixel_loss_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logit, target, n, kind, per_sample,
+    hipLaunchKernelGGL(pixel_loss_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, logit, target, n, kind, per_sample,
                        prob);
     SCM_LAUNCH_CHECK("pixel_loss_kernel");
     return SCM_OK;
@@ -252,32 +260,37 @@ __global__ void action_bias_kernel(const float* __restrict__ act, const float* _
 }
 // csum[b][co] = d sbias.  d_act[b][a] = scale * sum_co csum[b][co] * Wsum[co][a];
 // dW_eff[co][c0+a][tap] = sum_b act[b][a] * csum[b][co]  (same value for the 9 taps)
-__global__ void action_bias_bwd_kernel(const float* __restrict__ act, const float* __restrict__ w,
-                                       const float* __restrict__ scale, const float* __restrict__ csum, int B, int A,
-                                       int cout, int cin, int c0, float* __restrict__ d_act,
-                                       float* __restrict__ dw_eff) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(64) action_bias_bwd_kernel(const float* __restrict__ act, const float* __restrict__ w,
+                                                             const float* __restrict__ scale,
+                                                             const float* __restrict__ csum, int B, int A, int cout,
+                                                             int cin, int c0, float* __restrict__ d_act,
+                                                             float* __restrict__ dw_eff) {
+    // one wave per output element: blocks [0, B*A) -> d_act, blocks [B*A, B*A + cout*A) -> dw_eff
+    const int lane = threadIdx.x;
     const float sc = scale ? *scale : 1.f;
-    if (d_act && idx < B * A) {
+    int idx = blockIdx.x;
+    if (idx < B * A) {
+        if (!d_act) return;
         const int b = idx / A, a = idx - b * A;
         float s = 0.f;
-        for (int co = 0; co < cout; ++co) {
+        for (int co = lane; co < cout; co += 64) {
             const float* wp = w + ((size_t)co * cin + c0 + a) * 9;
             float ws = 0.f;
 #pragma unroll
             for (int t = 0; t < 9; ++t) ws += wp[t];
             s = fmaf(csum[(size_t)b * cout + co], ws, s);
         }
-        d_act[idx] = s * sc;
+        s = wave_sum(s);
+        if (lane == 0) d_act[idx] = s * sc;
+        return;
     }
-    if (dw_eff && idx < cout * A) {
-        const int co = idx / A, a = idx - co * A;
-        float s = 0.f;
-        for (int b = 0; b < B; ++b) s = fmaf(act[(size_t)b * A + a], csum[(size_t)b * cout + co], s);
-        float* d = dw_eff + ((size_t)co * cin + c0 + a) * 9;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) d[t] = s;
-    }
+    idx -= B * A;
+    if (!dw_eff || idx >= cout * A) return;
+    const int co = idx / A, a = idx - co * A;
+    float s = 0.f;
+    for (int b = lane; b < B; b += 64) s = fmaf(act[(size_t)b * A + a], csum[(size_t)b * cout + co], s);
+    s = wave_sum(s);
+    if (lane < 9) dw_eff[((size_t)co * cin + c0 + a) * 9 + lane] = s;
 }
 extern "C" int scm_action_bias(const float* act, const float* w, const float* scale, int B, int A, int cout, int cin,
                                int c0, float* sbias, void* stream) {
@@ -292,9 +305,7 @@ extern "C" int scm_action_bias_bwd(const float* act, const float* w, const float
                                    int A, int cout, int cin, int c0, float* d_act, float* dw_eff, void* stream) {
     SCM_REQUIRE(act && w && csum && (d_act || dw_eff) && B > 0 && A > 0 && cout > 0 && c0 >= 0 && c0 + A <= cin,
                 "scm_action_bias_bwd: bad arguments");
-    int total = B * A;
-    if (cout * A > total) total = cout * A;
-    hipLaunchKernelGGL(action_bias_bwd_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, act, w,
+    hipLaunchKernelGGL(action_bias_bwd_kernel, dim3(B * A + cout * A), dim3(64), 0, (hipStream_t)stream, act, w,
                        scale, csum, B, A, cout, cin, c0, d_act, dw_eff);
     SCM_LAUNCH_CHECK("action_bias_bwd_kernel");
     return SCM_OK;

@@ -130,7 +130,11 @@ def _convT_factor_sum(self, x, L, C):
     cin = w.shape[0]
     ws = ops.FactorSumFn.apply(w.reshape(cin, L * C, 3, 3), L, C)                    # (cin, C, 3, 3)
     bs = ops.FactorSumFn.apply(self.bias.reshape(1, L * C, 1, 1), L, C).reshape(C)   # (C,)
-    packs = ops.pack_conv3x3(ws, cin, C, True, cin, 0)
+    key = (w.data_ptr(), w._version, ops.weights_epoch(), w.device, L, C)
+    if getattr(self, "_fs_key", None) != key:           # packs depend on the weight values only
+        self._fs_packs = ops.pack_conv3x3(ws, cin, C, True, cin, 0)
+        self._fs_key = key
+    packs = self._fs_packs
     cfg = {"pad": ops.PAD_ZERO, "act": ops.ACT_NONE, "transposed": True, "packs": packs}
     return ops.Conv3x3Fn.apply(x, None, None, ws, bs, None, None, None, cfg)
 
