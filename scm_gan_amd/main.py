@@ -352,12 +352,15 @@ def compute_rollout_reward(z, transition, reward_predictor, num_actions,
     return max_r
 
 
+@torch.no_grad()
 def measure_prediction_mse(datasource, encoder, decoder, transition, reward_pred,
                            train_iter=0, timesteps=100, num_factors=16, experiment_name='default',
                            use_training_set=False, batch_size=100, write_files=True):
     """main.py:784-855: open-loop eval rollout, per-step masked pixel / reward MSE.
     Returns {'pixel': (means, stds), 'reward': (means, stds)} and, like the
-    reference's plot_error_graph (main.py:858-865), writes the mse_*.json files."""
+    reference's plot_error_graph (main.py:858-865), writes the mse_*.json files.
+    Runs under no_grad: the reference cuts the graph every step anyway (z.detach_(),
+    main.py:835) and SpectralNorm advances u/v regardless of grad mode."""
     start_time = time.time()
     num_actions = datasource.binary_input_channels
     states, rewards, dones, actions = datasource.get_trajectories(batch_size=batch_size, timesteps=timesteps,
