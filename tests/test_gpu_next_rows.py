@@ -20,10 +20,10 @@ def build(seed, C=3, A=5, R=2, L=16):
     from scm_gan_amd import models as M
     enc, dec, rp, disc, tr = M.Encoder(L, C), M.Decoder(L, C), M.RewardPredictor(L, R), M.Discriminator(), \
         M.Transition(L, A)
-    enc.load_state_dict(WS.to_torch(WS.encoder_state(seed)))
-    tr.load_state_dict(WS.to_torch(WS.transition_state(seed + 1)))
-    dec.load_state_dict(WS.to_torch(WS.decoder_state(seed + 2)))
-    rp.load_state_dict(WS.to_torch(WS.reward_state(seed + 3)))
+    enc.load_state_dict(WS.to_torch(WS.encoder_state(seed, color=C)))
+    tr.load_state_dict(WS.to_torch(WS.transition_state(seed + 1, actions=A)))
+    dec.load_state_dict(WS.to_torch(WS.decoder_state(seed + 2, color=C)))
+    rp.load_state_dict(WS.to_torch(WS.reward_state(seed + 3, rewards=R)))
     return enc, dec, rp, disc, tr
 
 
@@ -201,3 +201,17 @@ def test_short_training_run_is_stable_and_learns():
     for m in (enc, dec, rp, tr):
         for p in m.parameters():
             assert torch.isfinite(p).all()
+
+
+def test_excitation_backtrack_runs_and_attributes():
+    """excitation_bptt.py:6-53 numeric core: returns per-step action attributions and latent masks."""
+    from scm_gan_amd.excitation_bptt import excitation_backtrack
+    enc, dec, rp, disc, tr = build(90, A=4)
+    tr.train()
+    tr.seed_noise(3)
+    z = (torch.rand(1, 16, 16, 16, device="cuda") < 0.5).float()
+    out = excitation_backtrack(z, tr, rp, 4, steps=6, threshold=0.0)
+    assert out is not None and out["t"] == 0
+    assert len(out["action_attributions"]) == 1 and out["action_attributions"][0].shape == (1, 4)
+    m = out["latent_masks"][0]
+    assert m.shape == z.shape and float(m.max()) <= 1.0 and torch.isfinite(m).all()
