@@ -180,11 +180,16 @@ def main():
     ap.add_argument("--rewards", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--profile-mode", action="store_true",
+                    help="only the warm-up + timed training steps (no rollout check, decoder leg, CPU baseline, event "
+                         "brackets): the run to put under rocprofv3 so its per-kernel averages match the bench's")
     a = ap.parse_args()
     global H, W, C, A, R
     H = W = a.size
     C, A, R = a.channels, a.actions, a.rewards
     headline = (a.size, a.channels, a.actions, a.rewards, a.batch, a.horizon) == (64, 3, 5, 2, 64, 10)
+    if a.profile_mode:
+        a.no_kernel_timer = a.no_cpu_baseline = True
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -270,9 +275,9 @@ def main():
                                "share_of_step": s["ms"] / (dt * 1e3)}
             out["kernels"] = {k: {"launches": v["launches"], "ms_total": round(v["ms"], 3),
                                   "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12} for k, v in summ.items()}
-        if world == 1:
+        if world == 1 and not a.profile_mode:
             out["decoder"] = decoder_leg(dev, a.batch)
-        if world == 1 and headline:
+        if world == 1 and headline and not a.profile_mode:
             l1, flips = rollout_l1(dev)
             out["rollout_l1_vs_ref"] = l1
             out["rollout_latent_flips"] = flips

@@ -235,35 +235,12 @@ class Trainer(object):
             loss = loss + theta * lo_loss
 
         if enable_cf_shuffle_loss:
-            # main.py:242-262; z_cf_b aliases z_orig and is mutated in place there
-            z_cf_a = z.clone()
-            z_cf_b = z_orig
-            unswapped_factor_map = torch.ones((batch_size, latent_dim), device=states.device)
-            for i in range(batch_size):
-                idx_a = np.random.randint(latent_dim)
-                idx_b = np.random.randint(latent_dim)
-                unswapped_factor_map[i, idx_a] = 0
-                unswapped_factor_map[i, idx_b] = 0
-                z_cf_b[i, idx_a], z_cf_b[i, idx_b] = z_cf_b[i, idx_b], z_cf_b[i, idx_a]
-            for t in range(1, a.counterfactual_horizon):
-                z_cf_b = transition(z_cf_b, onehots[:, t])
-            cf_loss = torch.abs(z_cf_a - z_cf_b).mean(-1).mean(-1) * unswapped_factor_map
-            cf_loss = CF_REGULARIZATION_LAMBDA * torch.mean(cf_loss.mean(-1) * active_mask)
+            cf_loss = self._cf_disentanglement(z, z_orig, onehots, active_mask)
             loss = loss + cf_loss
             ts.collect('CF Disentanglement Loss', cf_loss)
 
         if enable_control_bias_loss:
-            # main.py:268-283
-            z_cf_a = z.clone()
-            z_cf_b = z_orig
-            cf_actions = np.array(actions).copy()
-            np.random.shuffle(cf_actions)
-            cf_onehots = onehot(cf_actions, self.num_actions)
-            for t in range(1, a.counterfactual_horizon):
-                z_cf_b = transition(z_cf_b, cf_onehots[:, t])
-            eps = .001
-            cf_loss = -torch.log(torch.abs(z_cf_a - z_cf_b).mean(-1).mean(-1).mean(-1) + eps)
-            cf_loss = CF_REGULARIZATION_LAMBDA * torch.mean(cf_loss * active_mask)
+            cf_loss = self._cf_action_control(z, z_orig, actions, active_mask)
             loss = loss + cf_loss
             ts.collect('CF Control Bias Loss', cf_loss)
 
@@ -279,6 +256,40 @@ class Trainer(object):
             self.opt_dec.step()
             self.opt_trans.step()
         return loss.detach()
+
+
+    def _rollout_counterfactual(self, z_start, step_onehots):
+        """Roll the encoded start state forward under a (counterfactual) action plan for
+        --counterfactual-horizon - 1 steps (main.py:255-257, 276-278)."""
+        z_cf = z_start
+        for t in range(1, self.a.counterfactual_horizon):
+            z_cf = self.transition(z_cf, step_onehots[:, t])
+        return z_cf
+
+    def _cf_disentanglement(self, z_factual, z_start, onehots, active_mask):
+        """Counterfactual disentanglement regulariser, main.py:242-262: swap two random latent
+        factors per sample in the start state (IN PLACE on z_start, which the reference also
+        mutates through its alias), replay the same actions, and penalise any change of the
+        factors that were not swapped."""
+        n, factors = z_factual.shape[0], self.latent_dim
+        keep = torch.ones((n, factors), device=z_factual.device)
+        for row in range(n):
+            fa, fb = np.random.randint(factors), np.random.randint(factors)
+            keep[row, fa] = 0
+            keep[row, fb] = 0
+            z_start[row, fa], z_start[row, fb] = z_start[row, fb], z_start[row, fa]
+        z_swapped = self._rollout_counterfactual(z_start, onehots)
+        drift = torch.abs(z_factual.clone() - z_swapped).mean(-1).mean(-1) * keep
+        return CF_REGULARIZATION_LAMBDA * torch.mean(drift.mean(-1) * active_mask)
+
+    def _cf_action_control(self, z_factual, z_start, actions, active_mask):
+        """Counterfactual action-control regulariser, main.py:268-283: replay the start state
+        under a shuffled action plan; the outcome should differ (negative log distance)."""
+        plan = np.array(actions).copy()
+        np.random.shuffle(plan)
+        z_other = self._rollout_counterfactual(z_start, onehot(plan, self.num_actions))
+        gap = torch.abs(z_factual.clone() - z_other).mean(-1).mean(-1).mean(-1)
+        return CF_REGULARIZATION_LAMBDA * torch.mean(-torch.log(gap + .001) * active_mask)
 
 
 def train(latent_dim, datasource, num_actions, num_rewards,

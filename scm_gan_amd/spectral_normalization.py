@@ -20,38 +20,33 @@ def l2normalize(v, eps=1e-12):
 
 
 class SpectralNorm(nn.Module):
+    """`SpectralNorm(module, name='weight', power_iterations=1)`: same constructor, same
+    parameters registered on the wrapped module (`<name>_u`, `<name>_v`, `<name>_bar`)."""
+
+    SUFFIXES = ("_u", "_v", "_bar")
+
     def __init__(self, module, name='weight', power_iterations=1):
         super(SpectralNorm, self).__init__()
-        self.module = module
-        self.name = name
-        self.power_iterations = power_iterations
+        self.module, self.name, self.power_iterations = module, name, power_iterations
         self._precomputed = []      # (sigma, inv_sigma) of power iterations already run (see precompute())
-        if not self._made_params():
-            self._make_params()
+        if not all(hasattr(module, name + s) for s in self.SUFFIXES):
+            self._install_parameters()
 
-    def _made_params(self):
-        try:
-            getattr(self.module, self.name + "_u")
-            getattr(self.module, self.name + "_v")
-            getattr(self.module, self.name + "_bar")
-            return True
-        except AttributeError:
-            return False
-
-    def _make_params(self):
-        # spectral_normalization.py:47-63: u, v ~ N(0,1) normalised; weight -> weight_bar
-        w = getattr(self.module, self.name)
-        height = w.data.shape[0]
-        width = w.view(height, -1).data.shape[1]
-        u = Parameter(w.data.new(height).normal_(0, 1), requires_grad=False)
-        v = Parameter(w.data.new(width).normal_(0, 1), requires_grad=False)
-        u.data = l2normalize(u.data)
-        v.data = l2normalize(v.data)
-        w_bar = Parameter(w.data)
-        del self.module._parameters[self.name]
-        self.module.register_parameter(self.name + "_u", u)
-        self.module.register_parameter(self.name + "_v", v)
-        self.module.register_parameter(self.name + "_bar", w_bar)
+    def _install_parameters(self):
+        """Replace `weight` by `weight_bar` plus the two power-iteration vectors
+        (u: rows, v: columns of the weight viewed as a matrix), unit-normalised draws
+        from N(0, 1) that never receive gradients -- spectral_normalization.py:47-63."""
+        weight = getattr(self.module, self.name)
+        rows = weight.shape[0]
+        cols = weight.numel() // rows
+        vectors = {}
+        for suffix, n in (("_u", rows), ("_v", cols)):
+            vec = weight.data.new_empty(n).normal_(0, 1)
+            vectors[suffix] = Parameter(l2normalize(vec), requires_grad=False)
+        self.module._parameters.pop(self.name)
+        self.module.register_parameter(self.name + "_u", vectors["_u"])
+        self.module.register_parameter(self.name + "_v", vectors["_v"])
+        self.module.register_parameter(self.name + "_bar", Parameter(weight.data))
 
     def _update_u_v(self):
         """Power iteration(s) on the device; returns (sigma, inv_sigma)."""
