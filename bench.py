@@ -24,6 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_F16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16/fp16 MFMA peak (opt-in --precision fp16 only)
 H = W = 64
 C, A, R, L = 3, 5, 2, 16      # BASELINE configs[1]; --size/--channels/--actions/--rewards select the other shapes
 
@@ -178,6 +179,10 @@ def main():
     ap.add_argument("--channels", type=int, default=3)
     ap.add_argument("--actions", type=int, default=5)
     ap.add_argument("--rewards", type=int, default=2)
+    ap.add_argument("--precision", choices=("fp32", "fp16"), default="fp32",
+                    help="MFMA operand precision of the 3x3 convs. fp32 (default) is the reference's arithmetic and the "
+                         "only valid headline; fp16 = opt-in fp16 forward / bf16 gradient operands with fp32 accumulation "
+                         "(BASELINE configs[4]), reported as a separate, non-headline line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--profile-mode", action="store_true",
@@ -187,7 +192,7 @@ def main():
     global H, W, C, A, R
     H = W = a.size
     C, A, R = a.channels, a.actions, a.rewards
-    headline = (a.size, a.channels, a.actions, a.rewards, a.batch, a.horizon) == (64, 3, 5, 2, 64, 10)
+    headline = (a.size, a.channels, a.actions, a.rewards, a.batch, a.horizon, a.precision) == (64, 3, 5, 2, 64, 10, "fp32")
     if a.profile_mode:
         a.no_kernel_timer = a.no_cpu_baseline = True
 
@@ -209,6 +214,7 @@ def main():
 
     from scm_gan_amd import main as M, ops
     from scm_gan_amd.datasource import SyntheticDatasource
+    ops.set_compute_precision(a.precision)
     opts = M.parser.parse_args(["--train-iters", str(a.steps + a.warmup), "--horizon-min", str(a.horizon),
                                 "--horizon-max", str(a.horizon), "--batch-size", str(a.batch)])
     enc, dec, rp, disc, tr = build_nets(0)          # identical replicas on every rank
@@ -249,10 +255,13 @@ def main():
             "metric": "predicted frames/sec/node (minipacman 64x64, horizon=10) + rollout L1 vs ref",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if a.precision == "fp32" else "f16 fwd / bf16 bwd MFMA operands, f32 accumulate + f32 tensors",
+            "data": "synthetic",
             "config": {"workload": "%s: %dx%dx%d frames, per-GPU batch %d, horizon %d, A=%d, R=%d, "
                                    "training iteration fwd+bwd+clip+Adam, reference loss (BCE + reward MSE), no "
-                                   "discriminator" % ("configs[1] minipacman-shaped" if headline else "non-headline shape",
+                                   "discriminator" % ("configs[1] minipacman-shaped" if headline else
+                                                      ("non-headline shape" if a.precision == "fp32" else
+                                                       "NON-HEADLINE opt-in 16-bit MFMA operands"),
                                                       H, W, C, a.batch, a.horizon, A, R),
                        "global_batch": a.batch * world, "horizon": a.horizon, "parallelism": "dp%d" % world},
             "algorithmic_tflops": value * algorithmic_gflop_per_frame(a.horizon) / 1e3,
@@ -269,8 +278,9 @@ def main():
                 traffic = pmc[key[0]]["hbm_traffic_bytes"] if key else None
             except Exception:
                 pass
-            out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
-                               "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+            peak = PEAK_F32_MFMA_TFLOPS if "h16" not in name else PEAK_F16_MFMA_TFLOPS
+            out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": peak,
+                               "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                                "launches": s["launches"], "avg_launch_us": s["ms"] * 1e3 / s["launches"],
                                "share_of_step": s["ms"] / (dt * 1e3)}
             out["kernels"] = {k: {"launches": v["launches"], "ms_total": round(v["ms"], 3),

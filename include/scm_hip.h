@@ -34,6 +34,12 @@ extern "C" {
 #define SCM_PAD_CIRCULAR 1  /* padding_mode='circular', 1 px/side: models.py:51-56 */
 
 /* activation fused in an epilogue, or its derivative applied on load */
+/* MFMA operand precision of the opt-in 16-bit conv variant (scm_conv3x3_h16): products
+ * of fp16 / bf16 roundings of the fp32 tensors, accumulated in fp32 */
+#define SCM_PREC_F32 0
+#define SCM_PREC_F16 1
+#define SCM_PREC_BF16 2
+
 #define SCM_ACT_NONE 0
 #define SCM_ACT_LRELU 1     /* F.leaky_relu(x), slope 0.01: models.py:77,146,... */
 #define SCM_ACT_SIGMOID 2   /* torch.sigmoid: models.py:103,155 */
@@ -127,6 +133,29 @@ typedef struct scm_conv3x3_wgrad_desc {
 int scm_conv3x3_wgrad_workspace(int B, int H, int W, int cin, int cout, size_t* part_floats,
                                 size_t* csum_floats);
 int scm_conv3x3_wgrad(const scm_conv3x3_wgrad_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Opt-in 16-bit-input / fp32-accumulate variant of scm_conv3x3 (no reference
+ * counterpart: the reference is fp32 only; BASELINE config 5 / SURVEY.md 8(d) name
+ * it as "fp16 MFMA").  Same descriptor, same fp32 NCHW tensors, same epilogue;
+ * `wpack` must come from scm_pack_conv3x3_weights_h16 in the same precision.
+ * The operands of every product are rounded (nearest-even) to `precision`
+ * while staged; sums are fp32.  Forward uses SCM_PREC_F16, the gradient
+ * convolution SCM_PREC_BF16 (fp32 exponent range: no loss scaling).
+ * Pack layout: [group][chunk of 16 ci][tap][h][m][32 lanes][8 halves], element j of
+ * lane l = W[co = g*32*CT + m*32 + l][ci = 16*chunk + 8*h + j][tap], zero padded.
+ * ---------------------------------------------------------------------- */
+size_t scm_conv3x3_pack_h16_bytes(int cin, int cout);
+int scm_pack_conv3x3_weights_h16(const float* w, int cin, int cout, int transposed_src, int w_cin_total, int w_ci0,
+                                 void* fwd_pack, int fwd_precision, void* dgrad_pack, int dgrad_precision,
+                                 void* stream);
+int scm_conv3x3_h16(const scm_conv3x3_desc* d, int precision, void* stream);
+
+/* scm_conv3x3_wgrad with the 128 co x 64 ci workgroup tiles (cout > 64, cin > 32) on 16-bit
+ * operands (dyp and x rounded to `precision` while staged; fp32 accumulation, fp32 partial slabs,
+ * the same fixed-order reduction, workspaces as scm_conv3x3_wgrad_workspace).  Other shapes
+ * run the fp32 kernels. */
+int scm_conv3x3_wgrad_h16(const scm_conv3x3_wgrad_desc* d, int precision, void* stream);
 
 /* ------------------------------------------------------------------------
  * Spectral normalisation (spectral_normalization.py:14-68).

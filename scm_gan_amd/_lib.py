@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libscmgan_hip.so")
 
 PAD_ZERO, PAD_CIRCULAR = 0, 1
 ACT_NONE, ACT_LRELU, ACT_SIGMOID = 0, 1, 2
+PREC_F32, PREC_F16, PREC_BF16 = 0, 1, 2
 
 c_float_p = ctypes.c_void_p  # raw device pointers travel as void*
 
@@ -90,8 +91,12 @@ def lib():
             "scm_conv3x3_pack_floats": [ci, ci],
             "scm_conv3x3": [vp, vp],
             "scm_pack_conv3x3_weights": [vp, ci, ci, ci, ci, ci, vp, vp, vp],
+            "scm_conv3x3_pack_h16_bytes": [ci, ci],
+            "scm_pack_conv3x3_weights_h16": [vp, ci, ci, ci, ci, ci, vp, ci, vp, ci, vp],
+            "scm_conv3x3_h16": [vp, ci, vp],
             "scm_conv3x3_wgrad_workspace": [ci, ci, ci, ci, ci, vp, vp],
             "scm_conv3x3_wgrad": [vp, vp],
+            "scm_conv3x3_wgrad_h16": [vp, ci, vp],
             "scm_sn_power_iter": [ci, vp, ci, vp],
             "scm_sn_fold_grad": [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp, vp],
             "scm_conv2d_fwd": [vp, vp],
@@ -118,7 +123,8 @@ def lib():
         for name, args in sigs.items():
             fn = getattr(L, name)      # raises AttributeError when the library lacks a declared symbol
             fn.argtypes = args
-            fn.restype = ctypes.c_size_t if name in ("scm_conv3x3_pack_floats", "scm_conv2d_bwd_workspace") \
+            fn.restype = ctypes.c_size_t if name in ("scm_conv3x3_pack_floats", "scm_conv2d_bwd_workspace",
+                                                  "scm_conv3x3_pack_h16_bytes") \
                 else ctypes.c_int
         L._scm_symbols = sorted(sigs) + ["scm_version", "scm_last_error"]
         _lib = L

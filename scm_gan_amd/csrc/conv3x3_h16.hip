@@ -1,0 +1,451 @@
+// 16-bit-input / fp32-accumulate variant of the 3x3 same-size convolution
+// (SURVEY.md section 7 step 10, section 8(d) "cfg5 (fp16 MFMA)"), opt-in.
+//
+// Same implicit GEMM, same NCHW fp32 tensors in HBM and the same epilogue as
+// conv3x3_mfma.hip; only the MFMA operands change: activations are rounded to
+// fp16 (forward) or bf16 (gradients: fp32's exponent range, no loss scaling)
+// while they are staged into LDS, weights are packed in that type once per
+// optimizer step, products accumulate in fp32 on v_mfma_f32_32x32x16_{f16,bf16}
+// (16x the f32 MFMA rate, so the kernel is HBM/L2-bound, not MFMA-bound).
+//
+//   MFMA A = weights  A[i = co (lane&31)][k = ci 8*(lane>>5)+j]   8 halves (16 B) per lane
+//   MFMA B = pixels   B[k = ci 8*(lane>>5)+j][j = pixel (lane&31)]
+//   D as in the f32 kernel: col = pixel, row = (r&3) + 8*(r>>2) + 4*(lane>>5) = co.
+//
+// K chunks of 16 input channels.  A thread stages halo element e for all 16
+// channels of the chunk, so the channel-innermost LDS image the B operand needs
+// ([ci half h][element e][8 channels] = one 16-byte unit per element) is a plain
+// ds_write_b128 of the thread's own registers: no transpose pass.  Consecutive
+// lanes read/write consecutive 16-byte units: conflict-free.
+//
+// Workgroup = 4 waves x PT=4 pixel tiles = 512 pixels x CT*32 output channels,
+// one workgroup per CU (256 accumulator registers + the prefetch registers of a
+// 16-channel chunk), two LDS stages when they fit.
+#include <type_traits>
+#include "conv_args.h"
+
+#define HKC 16
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 b16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 b16x2 __attribute__((ext_vector_type(2)));
+
+template <int PREC>
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {
+    if constexpr (PREC == SCM_PREC_F16) {
+        h16x2 v = {(_Float16)lo, (_Float16)hi};
+        return __builtin_bit_cast(unsigned, v);
+    } else {
+        b16x2 v = {(__bf16)lo, (__bf16)hi};
+        return __builtin_bit_cast(unsigned, v);
+    }
+}
+
+template <int PREC>
+__device__ __forceinline__ f32x16 mfma_h16(u32x4 a, u32x4 b, f32x16 c) {
+    if constexpr (PREC == SCM_PREC_F16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b16x8, a), __builtin_bit_cast(b16x8, b), c, 0, 0, 0);
+}
+
+template <int PREC, int CT, int PT, int NJ, bool GATED>
+__global__ void __launch_bounds__(256, 1) conv3x3_h16_kernel(const ConvKArgs a) {
+    extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
+    constexpr int CW = CT * 32;
+    constexpr int WU = 9 * 2 * CT * 32;            // 16-byte units of a weight chunk: [tap][h][m][lane]
+    constexpr int WR = (WU + 255) / 256;
+    constexpr int NPW = PT * 32, NP = 4 * NPW;
+    constexpr int PLANE = NJ * 256;                // units per channel half
+    constexpr int STAGE = WR * 256 + 2 * PLANE;    // units per LDS stage
+    constexpr bool DB = 2 * STAGE * 16 <= 160 * 1024;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int W = a.W, H = a.H, HW = H * W;
+    const int ROWPL = W + 2;
+
+    const int b = blockIdx.x / a.tiles_per_img;
+    const int tile = blockIdx.x - b * a.tiles_per_img;
+    const int cg = blockIdx.y;
+    const int p0 = tile * NP;
+    const int r0 = p0 / W;
+    int plast = p0 + NP;
+    if (plast > HW) plast = HW;
+    const int nrows = (plast - 1) / W - r0 + 3;
+    const int nelem = nrows * ROWPL;
+
+    int goff[NJ];
+    unsigned okmask = 0u;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int e = tid + 256 * j;
+        int g = 0;
+        if (e < nelem) {
+            const int r = e / ROWPL;
+            const int c = e - r * ROWPL;
+            int iy = r0 - 1 + r, ix = c - 1;
+            bool ok = true;
+            if (a.pad_mode == SCM_PAD_CIRCULAR) {
+                iy = iy < 0 ? iy + H : (iy >= H ? iy - H : iy);
+                ix = ix < 0 ? ix + W : (ix >= W ? ix - W : ix);
+            } else {
+                ok = (iy >= 0 && iy < H && ix >= 0 && ix < W);
+            }
+            iy = iy < 0 ? 0 : (iy >= H ? H - 1 : iy);
+            ix = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
+            g = iy * W + ix;
+            if (ok) okmask |= 1u << j;
+        }
+        goff[j] = g;
+    }
+
+    int baddr[PT];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        int p = p0 + wave * NPW + pt * 32 + l31;
+        if (p > HW - 1) p = HW - 1;
+        const int y = p / W;
+        const int x = p - y * W;
+        baddr[pt] = lh * PLANE + (y - r0) * ROWPL + x;
+    }
+
+    f32x16 acc[CT][PT];
+#pragma unroll
+    for (int m = 0; m < CT; ++m)
+#pragma unroll
+        for (int n = 0; n < PT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    const int cin = a.c1 + a.c2;
+    const int nchunks = (cin + HKC - 1) / HKC;
+    const u32x4* wsrc = reinterpret_cast<const u32x4*>(a.wpack) + (size_t)cg * nchunks * WU;
+    const int wtotal = nchunks * WU;
+    const int gate_act = GATED ? a.gate_act : 0;
+
+    unsigned pw[WR][4];
+    float px[HKC][NJ], pg[GATED ? HKC : 1][GATED ? NJ : 1];
+
+    auto fetch = [&](int ci0) {
+#pragma unroll
+        for (int k = 0; k < WR; ++k) {
+            int gi = (ci0 / HKC) * WU + tid + 256 * k;
+            gi = gi < wtotal ? gi : wtotal - 1;
+            const u32x4 t = wsrc[gi];
+            pw[k][0] = t[0]; pw[k][1] = t[1]; pw[k][2] = t[2]; pw[k][3] = t[3];
+        }
+#pragma unroll
+        for (int c = 0; c < HKC; ++c) {
+            const int ci = ci0 + c;
+            const int cc = ci < cin ? ci : 0;
+            const bool first = cc < a.c1;
+            const size_t o = first ? ((size_t)b * a.c1 + cc) * HW : ((size_t)b * a.c2 + (cc - a.c1)) * HW;
+            const float* src = (first ? a.x1 : a.x2) + o;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) px[c][j] = src[goff[j]];
+            if constexpr (GATED) {
+                const float* gsrc = (first ? a.gate1 : a.gate2) + o;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) pg[c][j] = gsrc[goff[j]];
+            }
+        }
+    };
+    auto store = [&](int ci0, int buf) {
+        u32x4* wl = smem16 + buf * STAGE;
+        u32x4* xl = wl + WR * 256;
+#pragma unroll
+        for (int k = 0; k < WR; ++k) {
+            u32x4 v;
+            v[0] = pw[k][0]; v[1] = pw[k][1]; v[2] = pw[k][2]; v[3] = pw[k][3];
+            wl[tid + 256 * k] = v;                 // channels >= cin are zero in the pack
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const bool ok = (okmask >> j) & 1u;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int c = 8 * h + i;
+                    float t = px[c][j];
+                    if constexpr (GATED) t *= scm_act_grad_from_out(pg[c][j], gate_act);
+                    v[i] = (ok && ci0 + c < cin) ? t : 0.f;
+                }
+                u32x4 u;
+                u[0] = pack2<PREC>(v[0], v[1]); u[1] = pack2<PREC>(v[2], v[3]);
+                u[2] = pack2<PREC>(v[4], v[5]); u[3] = pack2<PREC>(v[6], v[7]);
+                xl[h * PLANE + tid + 256 * j] = u;
+            }
+        }
+    };
+    auto mfma_taps = [&](int buf, auto t0c, auto t1c) {
+        const u32x4* wl = smem16 + buf * STAGE;
+        const u32x4* xl = wl + WR * 256;
+        constexpr int T0 = decltype(t0c)::value, T1 = decltype(t1c)::value;
+#pragma unroll
+        for (int tap = T0; tap < T1; ++tap) {
+            const int toff = (tap / 3) * ROWPL + (tap % 3);
+            u32x4 av[CT], bv[PT];
+#pragma unroll
+            for (int m = 0; m < CT; ++m) av[m] = wl[((tap * 2 + lh) * CT + m) * 32 + l31];
+#pragma unroll
+            for (int n = 0; n < PT; ++n) bv[n] = xl[baddr[n] + toff];
+#pragma unroll
+            for (int m = 0; m < CT; ++m)
+#pragma unroll
+                for (int n = 0; n < PT; ++n) acc[m][n] = mfma_h16<PREC>(av[m], bv[n], acc[m][n]);
+        }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I4 = std::integral_constant<int, 4>;
+    using I9 = std::integral_constant<int, 9>;
+
+    if constexpr (DB) {
+        fetch(0);
+        store(0, 0);
+        if (HKC < cin) fetch(HKC);
+        __syncthreads();
+        int cur = 0;
+        for (int ci0 = 0; ci0 < cin; ci0 += HKC) {
+            mfma_taps(cur, I0{}, I4{});
+            if (ci0 + HKC < cin) store(ci0 + HKC, cur ^ 1);
+            if (ci0 + 2 * HKC < cin) fetch(ci0 + 2 * HKC);
+            mfma_taps(cur, I4{}, I9{});
+            __syncthreads();
+            cur ^= 1;
+        }
+    } else {
+        fetch(0);
+        for (int ci0 = 0; ci0 < cin; ci0 += HKC) {
+            __syncthreads();
+            store(ci0, 0);
+            __syncthreads();
+            if (ci0 + HKC < cin) fetch(ci0 + HKC);
+            mfma_taps(0, I0{}, I9{});
+        }
+    }
+
+    // ---- epilogue (as conv3x3_mfma.hip): scale, bias, per-sample bias, activation, NCHW store
+    const float sc = a.scale ? *a.scale : 1.f;
+    const int co2n = a.cout - a.co1;
+    float badd[CT][16];
+#pragma unroll
+    for (int m = 0; m < CT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) badd[m][r] = 0.f;
+    if (a.bias) {
+#pragma unroll
+        for (int m = 0; m < CT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = cg * CW + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                badd[m][r] += a.bias[co < a.cout ? co : a.cout - 1];
+            }
+    }
+    if (a.sbias) {
+#pragma unroll
+        for (int m = 0; m < CT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = cg * CW + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                badd[m][r] += a.sbias[(size_t)b * a.cout + (co < a.cout ? co : a.cout - 1)];
+            }
+    }
+    // The accumulator layout (lane -> pixel, register -> channel) gives 128-byte store segments
+    // and one store instruction per register: ~85 cycles of the CU's store path each, 36 us per
+    // workgroup at CT = 4.  Each wave transposes its 32-channel x 128-pixel slab through its own
+    // LDS region instead and stores float4s: whole 512-byte row runs, a quarter of the instructions.
+    constexpr int EP = NPW + 4;                     // floats per channel row (+16 B: rows on different banks)
+    float* ep = reinterpret_cast<float*>(smem16) + wave * (32 * EP);
+    const bool vec = (HW & 3) == 0;
+    __syncthreads();                                // every wave is done reading the stage buffers
+#pragma unroll
+    for (int m = 0; m < CT; ++m) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+#pragma unroll
+            for (int n = 0; n < PT; ++n) ep[row * EP + n * 32 + l31] = scm_act(acc[m][n][r] * sc + badd[m][r], a.act);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int row = 2 * k + lh;
+            const int co = cg * CW + m * 32 + row;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(ep + row * EP + 4 * l31);
+            const int p = p0 + wave * NPW + 4 * l31;
+            if (co < a.cout) {
+                float* dst = (co < a.co1 ? a.y1 + ((size_t)b * a.co1 + co) * HW
+                                         : a.y2 + ((size_t)b * co2n + (co - a.co1)) * HW) + p;
+                if (vec && p + 3 < HW) {
+                    *reinterpret_cast<f32x4*>(dst) = v;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (p + i < HW) dst[i] = v[i];
+                }
+            }
+        }
+        if (m + 1 < CT) __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------ pack
+// [group][chunk of 16 ci][tap][h][m][32 lanes][8]: element j of the unit of lane l holds
+// Wc[co = g*CW + m*32 + l][ci = 16*chunk + 8*h + j][tap]; zero beyond cout / cin.
+static inline int h16_ct(int cout) { return cout <= 32 ? 1 : (cout <= 64 ? 2 : 4); }
+
+static size_t h16_pack_halves(int cin, int cout) {
+    const int ct = h16_ct(cout), cw = ct * 32;
+    const int ng = (cout + cw - 1) / cw, nch = (cin + HKC - 1) / HKC;
+    return (size_t)ng * nch * 9 * 2 * ct * 32 * 8;
+}
+
+__global__ void pack_conv3x3_h16_kernel(const float* __restrict__ w, int cin, int cout, int transposed_src, int wct,
+                                        int wc0, unsigned short* __restrict__ fwd, int fprec,
+                                        unsigned short* __restrict__ dgr, int dprec, int nf, int nd) {
+    auto Wc = [&](int co, int ci, int t) -> float {
+        return transposed_src ? w[((size_t)(wc0 + ci) * cout + co) * 9 + (8 - t)]
+                              : w[((size_t)co * wct + wc0 + ci) * 9 + t];
+    };
+    auto cvt = [](float v, int prec) -> unsigned short {
+        if (prec == SCM_PREC_F16) return __builtin_bit_cast(unsigned short, (_Float16)v);
+        return __builtin_bit_cast(unsigned short, (__bf16)v);
+    };
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    // decode idx for a conv with `ko` output and `ki` input channels
+    auto decode = [&](int e, int ko, int ki, int& o, int& i, int& tap) {
+        const int ct = ko <= 32 ? 1 : (ko <= 64 ? 2 : 4);
+        const int nch = (ki + HKC - 1) / HKC;
+        const int j = e % 8; e /= 8;
+        const int l = e % 32; e /= 32;
+        const int m = e % ct; e /= ct;
+        const int h = e % 2; e /= 2;
+        tap = e % 9; e /= 9;
+        const int ch = e % nch; e /= nch;
+        o = e * ct * 32 + m * 32 + l;
+        i = ch * HKC + 8 * h + j;
+    };
+    if (fwd && idx < nf) {
+        int co, ci, tap;
+        decode(idx, cout, cin, co, ci, tap);
+        fwd[idx] = cvt((co < cout && ci < cin) ? Wc(co, ci, tap) : 0.f, fprec);
+    }
+    if (dgr && idx < nd) {
+        // dgrad conv: input channels = cout, output channels = cin, taps flipped
+        int o, i, tap;
+        decode(idx, cin, cout, o, i, tap);
+        dgr[idx] = cvt((o < cin && i < cout) ? Wc(i, o, 8 - tap) : 0.f, dprec);
+    }
+}
+
+extern "C" size_t scm_conv3x3_pack_h16_bytes(int cin, int cout) {
+    if (cin <= 0 || cout <= 0) return 0;
+    return h16_pack_halves(cin, cout) * 2;
+}
+
+extern "C" int scm_pack_conv3x3_weights_h16(const float* w, int cin, int cout, int transposed_src, int w_cin_total,
+                                            int w_ci0, void* fwd_pack, int fwd_precision, void* dgrad_pack,
+                                            int dgrad_precision, void* stream) {
+    SCM_REQUIRE(w && cin > 0 && cout > 0, "scm_pack_conv3x3_weights_h16: bad arguments (cin=%d cout=%d)", cin, cout);
+    if (w_cin_total == 0) w_cin_total = cin;
+    SCM_REQUIRE(w_ci0 >= 0 && w_ci0 + cin <= w_cin_total, "scm_pack_conv3x3_weights_h16: bad channel slice");
+    SCM_REQUIRE(fwd_pack || dgrad_pack, "scm_pack_conv3x3_weights_h16: no output requested");
+    SCM_REQUIRE(!fwd_pack || fwd_precision == SCM_PREC_F16 || fwd_precision == SCM_PREC_BF16,
+                "scm_pack_conv3x3_weights_h16: bad forward precision %d", fwd_precision);
+    SCM_REQUIRE(!dgrad_pack || dgrad_precision == SCM_PREC_F16 || dgrad_precision == SCM_PREC_BF16,
+                "scm_pack_conv3x3_weights_h16: bad dgrad precision %d", dgrad_precision);
+    const int nf = fwd_pack ? (int)h16_pack_halves(cin, cout) : 0;
+    const int nd = dgrad_pack ? (int)h16_pack_halves(cout, cin) : 0;
+    const int n = nf > nd ? nf : nd;
+    hipLaunchKernelGGL(pack_conv3x3_h16_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, cin, cout,
+                       transposed_src, w_cin_total, w_ci0, (unsigned short*)fwd_pack, fwd_precision,
+                       (unsigned short*)dgrad_pack, dgrad_precision, nf, nd);
+    SCM_LAUNCH_CHECK("pack_conv3x3_h16_kernel");
+    return SCM_OK;
+}
+
+// ------------------------------------------------------------------ launch
+template <int PREC, int CT, int NJ, bool GATED>
+static int launch_h16_nj(const ConvKArgs& a, int groups, hipStream_t s) {
+    constexpr int WR = (9 * 2 * CT * 32 + 255) / 256;
+    constexpr size_t stage = ((size_t)WR * 256 + 2 * NJ * 256) * 16;
+    constexpr size_t ep_bytes = 4 * 32 * (128 + 4) * sizeof(float);      // epilogue transpose slabs
+    constexpr size_t lds_main = 2 * stage <= 160 * 1024 ? 2 * stage : stage;
+    constexpr size_t lds = lds_main > ep_bytes ? lds_main : ep_bytes;
+    static_assert(lds <= 160 * 1024, "halo tile exceeds the LDS");
+    auto kern = conv3x3_h16_kernel<PREC, CT, 4, NJ, GATED>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        int rc = scm_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+                               "hipFuncSetAttribute");
+        if (rc) return rc;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.B * a.tiles_per_img, groups), dim3(256), lds, s, a);
+    SCM_LAUNCH_CHECK("conv3x3_h16_kernel");
+    return SCM_OK;
+}
+
+template <int PREC, int CT>
+static int launch_h16(const ConvKArgs& k, int groups, hipStream_t s) {
+    constexpr int NP = 512;
+    ConvKArgs a = k;
+    const int HW = a.H * a.W;
+    a.tiles_per_img = (HW + NP - 1) / NP;
+    int rows = (NP % a.W == 0) ? NP / a.W : (NP + a.W - 2) / a.W + 1;
+    if (rows > a.H) rows = a.H;
+    a.plane = (rows + 2) * (a.W + 2);
+    const bool gated = a.gate_act != 0;
+    if (a.plane <= 3 * 256)
+        return gated ? launch_h16_nj<PREC, CT, 3, true>(a, groups, s) : launch_h16_nj<PREC, CT, 3, false>(a, groups, s);
+    if (a.plane <= 4 * 256)
+        return gated ? launch_h16_nj<PREC, CT, 4, true>(a, groups, s) : launch_h16_nj<PREC, CT, 4, false>(a, groups, s);
+    if (a.plane <= 6 * 256)
+        return gated ? launch_h16_nj<PREC, CT, 6, true>(a, groups, s) : launch_h16_nj<PREC, CT, 6, false>(a, groups, s);
+    scm_set_error("scm_conv3x3_h16: image width %d too large for the halo staging map", a.W);
+    return SCM_EUNSUPPORTED;
+}
+
+template <int PREC>
+static int launch_h16_ct(const ConvKArgs& k, hipStream_t s) {
+    const int ct = h16_ct(k.cout);
+    const int groups = (k.cout + ct * 32 - 1) / (ct * 32);
+    if (ct == 4) return launch_h16<PREC, 4>(k, groups, s);
+    if (ct == 2) return launch_h16<PREC, 2>(k, groups, s);
+    return launch_h16<PREC, 1>(k, groups, s);
+}
+
+extern "C" int scm_conv3x3_h16(const scm_conv3x3_desc* d, int precision, void* stream) {
+    SCM_REQUIRE(d != nullptr, "scm_conv3x3_h16: null descriptor");
+    SCM_REQUIRE(precision == SCM_PREC_F16 || precision == SCM_PREC_BF16, "scm_conv3x3_h16: bad precision %d", precision);
+    SCM_REQUIRE(d->x1 && d->c1 > 0, "scm_conv3x3_h16: x1/c1 required");
+    SCM_REQUIRE((d->x2 != nullptr) == (d->c2 > 0) && d->c2 >= 0, "scm_conv3x3_h16: x2/c2 mismatch");
+    SCM_REQUIRE(d->wpack && d->cout > 0, "scm_conv3x3_h16: wpack/cout required");
+    SCM_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0, "scm_conv3x3_h16: bad shape B=%d H=%d W=%d", d->B, d->H, d->W);
+    SCM_REQUIRE(d->y1 && d->co1 > 0 && d->co1 <= d->cout, "scm_conv3x3_h16: y1/co1 invalid");
+    SCM_REQUIRE((d->co1 == d->cout) || d->y2, "scm_conv3x3_h16: y2 required when co1 < cout");
+    SCM_REQUIRE(d->pad_mode == SCM_PAD_ZERO || d->pad_mode == SCM_PAD_CIRCULAR, "scm_conv3x3_h16: bad pad_mode %d",
+                d->pad_mode);
+    SCM_REQUIRE(d->act >= 0 && d->act <= 2 && d->gate_act >= 0 && d->gate_act <= 2, "scm_conv3x3_h16: bad act");
+    if (d->gate_act) {
+        SCM_REQUIRE(d->gate1 && (d->c2 == 0 || d->gate2), "scm_conv3x3_h16: gate tensors required with gate_act");
+    }
+    ConvKArgs k;
+    k.x1 = d->x1; k.x2 = d->x2; k.c1 = d->c1; k.c2 = d->c2;
+    k.gate1 = d->gate1; k.gate2 = d->gate2; k.gate_act = d->gate_act;
+    k.wpack = d->wpack; k.cout = d->cout;
+    k.scale = d->scale; k.bias = d->bias; k.sbias = d->sbias;
+    k.y1 = d->y1; k.y2 = d->y2; k.co1 = d->co1;
+    k.B = d->B; k.H = d->H; k.W = d->W; k.pad_mode = d->pad_mode; k.act = d->act;
+    k.tiles_per_img = 0; k.plane = 0;
+    hipStream_t s = (hipStream_t)stream;
+    return precision == SCM_PREC_F16 ? launch_h16_ct<SCM_PREC_F16>(k, s) : launch_h16_ct<SCM_PREC_BF16>(k, s);
+}

@@ -17,17 +17,9 @@
 // slab part[split][tap][co][ci]; a second kernel sums the slabs in a fixed
 // order (bitwise reproducible, no float atomics).  Per-sample channel sums of
 // dyp (bias gradient, action-plane gradients) fall out of the A operands.
-#include "common.h"
+#include "wgrad_args.h"
 #include <type_traits>
 
-struct WgradKArgs {
-    const float* x1; const float* x2; int c1; int c2;
-    const float* dy; const float* gate; int gate_act; int cout;
-    float* part; float* csum_part;
-    int B; int H; int W; int pad_mode;
-    int spi; int rows_per_split; int nseg; int PS;
-    int ci_groups;
-};
 
 // WM x WN waves (8 = two per SIMD for the big layers); wave (wm, wn) owns co tile
 // wm and NTW ci tiles, i.e. 9*NTW accumulator tiles of 16 registers.  NTW = 1 keeps
@@ -534,9 +526,6 @@ __global__ void __launch_bounds__(1024) csum_reduce_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------ host
-struct WgradPlan {
-    int mt, nt, spi, rows_per_split, nseg, PS, co_groups, ci_groups, nsplit, m16;
-};
 
 static int wgrad_plan(int B, int H, int W, int cin, int cout, WgradPlan* p) {
     const int cot = (cout + 31) / 32, cit = (cin + 31) / 32;
@@ -591,7 +580,7 @@ static int launch_wgrad(const WgradKArgs& a, const WgradPlan& p, hipStream_t s) 
     return SCM_OK;
 }
 
-extern "C" int scm_conv3x3_wgrad(const scm_conv3x3_wgrad_desc* d, void* stream) {
+static int wgrad_impl(const scm_conv3x3_wgrad_desc* d, int precision, void* stream) {
     SCM_REQUIRE(d != nullptr, "scm_conv3x3_wgrad: null descriptor");
     SCM_REQUIRE(d->x1 && d->c1 > 0, "scm_conv3x3_wgrad: x1/c1 required");
     SCM_REQUIRE((d->x2 != nullptr) == (d->c2 > 0) && d->c2 >= 0, "scm_conv3x3_wgrad: x2/c2 mismatch");
@@ -630,6 +619,8 @@ extern "C" int scm_conv3x3_wgrad(const scm_conv3x3_wgrad_desc* d, void* stream) 
         hipLaunchKernelGGL(kern, dim3(p.nsplit, p.co_groups * p.ci_groups), dim3(512), lds, s, a);
         SCM_LAUNCH_CHECK("conv3x3_wgrad_m16_kernel");
         rc = SCM_OK;
+    } else if (precision != SCM_PREC_F32 && p.mt == 4 && p.nt == 2) {
+        rc = scm_launch_wgrad_h16(a, p, precision, s);      // 128 co x 64 ci tiles on the 16-bit MFMA (conv3x3_wgrad_h16.hip)
     } else if (p.mt == 4) rc = p.nt == 2 ? launch_wgrad<4, 2, 1>(a, p, s) : launch_wgrad<4, 1, 1>(a, p, s);
     else if (p.mt == 2) rc = p.nt == 4 ? launch_wgrad<2, 4, 1>(a, p, s) : launch_wgrad<2, 2, 1>(a, p, s);
     else rc = launch_wgrad<1, 4, 1>(a, p, s);
@@ -647,4 +638,16 @@ extern "C" int scm_conv3x3_wgrad(const scm_conv3x3_wgrad_desc* d, void* stream) 
         SCM_LAUNCH_CHECK("csum_reduce_kernel");
     }
     return SCM_OK;
+}
+
+extern "C" int scm_conv3x3_wgrad(const scm_conv3x3_wgrad_desc* d, void* stream) {
+    return wgrad_impl(d, SCM_PREC_F32, stream);
+}
+
+// Opt-in: the 128 co x 64 ci workgroup tiles run on bf16/fp16 operands (fp32 accumulate, fp32
+// partial slabs and reduction); every other shape uses the fp32 kernels above.
+extern "C" int scm_conv3x3_wgrad_h16(const scm_conv3x3_wgrad_desc* d, int precision, void* stream) {
+    SCM_REQUIRE(precision == SCM_PREC_F16 || precision == SCM_PREC_BF16, "scm_conv3x3_wgrad_h16: bad precision %d",
+                precision);
+    return wgrad_impl(d, precision, stream);
 }

@@ -1,0 +1,292 @@
+// Weight gradient of the 3x3 same-size convolution on the 16-bit MFMA
+// (opt-in variant of conv3x3_wgrad.hip; same work split, same fp32 partial slabs
+// part[split][tap][co][ci], same fixed-order reduction, same per-sample channel sums).
+//
+//   dWc[co][ci][tap] = sum_{b,p} dyp[b,co,p] * Xpad[b,ci,p+tap],  dyp = dy * act'(y)
+//
+// GEMM view: M = co, N = ci (one 32x32 tile per tap), K = pixels, on
+// v_mfma_f32_32x32x16_bf16: a lane's fragment is 8 CONSECUTIVE k = 8 consecutive
+// pixels of one image row for one channel (16 bytes).  NCHW rows give exactly that
+// for the centre tap; the kx = 0 / 2 taps need the row shifted by one pixel, which
+// would be a misaligned 16-byte LDS read (replayed at 64 cycles).  So the staging
+// pass, which holds pixels p0-1 .. p0+8 of its channel row in registers anyway,
+// writes THREE images of every x row (shifted by -1, 0, +1 pixel): every B fragment
+// of every tap is then one aligned ds_read_b128, and circular / zero padding is
+// resolved once, while staging.
+//
+// Workgroup = 8 waves (two per SIMD), wave (wm, wn) owns co tile wm of 4 and ci tile
+// wn of 2 with its 9 tap accumulators (144 registers); it walks a band of rows of one
+// image: x rows in 4 rolling LDS slots (one new row per step), the dyp row double
+// buffered, one barrier per row.  The kernel is HBM-bound (x + dy + gate are read
+// once per ci group), the MFMAs take about a third of its time.
+#include "wgrad_args.h"
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 b16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 b16x2 __attribute__((ext_vector_type(2)));
+
+template <int PREC>
+__device__ __forceinline__ unsigned wpack2(float lo, float hi) {
+    if constexpr (PREC == SCM_PREC_F16) {
+        h16x2 v = {(_Float16)lo, (_Float16)hi};
+        return __builtin_bit_cast(unsigned, v);
+    } else {
+        b16x2 v = {(__bf16)lo, (__bf16)hi};
+        return __builtin_bit_cast(unsigned, v);
+    }
+}
+
+template <int PREC>
+__device__ __forceinline__ f32x16 wmfma(u32x4 a, u32x4 b, f32x16 c) {
+    if constexpr (PREC == SCM_PREC_F16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b16x8, a), __builtin_bit_cast(b16x8, b), c, 0, 0, 0);
+}
+
+#define WG_NG 8                    // 8-pixel groups per row segment (PS <= 64)
+#define WG_XP 65                   // ci pitch of an x image (units): 8 lanes x stride 65 units hit 8 different bank quads
+#define WG_DP 129                  // co pitch of the dyp image
+#define WG_XSLOT (3 * WG_NG * WG_XP)   // units per x row slot: [kx][g][ci]
+#define WG_DSTAGE (WG_NG * WG_DP)      // units per dyp stage: [g][co]
+
+// VEC: W % 4 == 0 and PS % 8 == 0 -> every 8-pixel group is two aligned float4 loads
+template <int PREC, bool VEC>
+__global__ void __launch_bounds__(512, 1) conv3x3_wgrad_h16_kernel(const WgradKArgs a) {
+    extern __shared__ __attribute__((aligned(16))) u32x4 wsm[];
+    u32x4* xs = wsm;                         // [4 slots][3][WG_NG][WG_XP]
+    u32x4* dsm = wsm + 4 * WG_XSLOT;         // [2][WG_NG][WG_DP]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int W = a.W, H = a.H, HW = H * W;
+    const int PS = a.PS;
+
+    const int split = blockIdx.x;
+    const int b = split / a.spi;
+    const int si = split - b * a.spi;
+    const int y_begin = si * a.rows_per_split;
+    int y_end = y_begin + a.rows_per_split;
+    if (y_end > H) y_end = H;
+    const int cig = blockIdx.y % a.ci_groups;
+    const int cog = blockIdx.y / a.ci_groups;
+    const int co_base = cog * 128, ci_base = cig * 64;
+    const int cin = a.c1 + a.c2;
+    const bool circ = a.pad_mode == SCM_PAD_CIRCULAR;
+    const int gate_act = a.gate_act;
+    const bool gated = gate_act != 0;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // ---- staging roles
+    // x: one (channel, group) task per thread: channel xc = tid >> 3, group xg = tid & 7
+    const int xc = tid >> 3, xg = tid & 7;
+    const int xci = ci_base + xc;
+    const bool xvalid = xci < cin;
+    const int xcc = xvalid ? xci : 0;
+    const float* xsrc = xcc < a.c1 ? a.x1 + ((size_t)b * a.c1 + xcc) * HW : a.x2 + ((size_t)b * a.c2 + (xcc - a.c1)) * HW;
+    // dyp: two tasks per thread: channel dc = (tid >> 3) + 64 j, group dg = tid & 7
+    const int dg = tid & 7;
+    const float* dsrc[2];
+    const float* gsrc[2];
+    bool dvalid[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int co = co_base + (tid >> 3) + 64 * j;
+        dvalid[j] = co < a.cout;
+        const size_t o = ((size_t)b * a.cout + (dvalid[j] ? co : 0)) * HW;
+        dsrc[j] = a.dy + o;
+        gsrc[j] = (gated ? a.gate : a.dy) + o;
+    }
+    float csum[2] = {0.f, 0.f};
+    const bool do_csum = a.csum_part != nullptr && cig == 0;
+
+    float px[10];                 // pixels p0-1 .. p0+8 of the x row
+    float pd[2][8], pgv[2][8];
+
+    for (int seg = 0; seg < a.nseg; ++seg) {
+        const int x0 = seg * PS;
+        int ps = W - x0;
+        if (ps > PS) ps = PS;
+        const int nks = (ps + 15) >> 4;          // 16-pixel K steps of a row segment
+
+        // 8 consecutive pixels starting at image column c0 of row pointer `row`:
+        // unconditional loads on clamped addresses; masks are applied by the callers.
+        auto load8 = [&](const float* row, int c0, float* v) {
+            if constexpr (VEC) {
+                const int cc = c0 + 7 < W ? c0 : W - 8;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(row + cc);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(row + cc + 4);
+                v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+                v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int c = c0 + i;
+                    v[i] = row[c < W ? c : W - 1];
+                }
+            }
+        };
+        const int xc0 = x0 + 8 * xg;             // first image column of this thread's x group
+        const int dc0 = x0 + 8 * dg;
+
+        auto fetch_x = [&](int r) {              // image row r (may be -1 or H)
+            int ri = r;
+            if (circ) ri = r < 0 ? r + H : (r >= H ? r - H : r);
+            ri = ri < 0 ? 0 : (ri >= H ? H - 1 : ri);
+            const float* row = xsrc + (size_t)ri * W;
+            load8(row, xc0, px + 1);
+            int cl = xc0 - 1, cr = xc0 + 8;
+            if (circ) {
+                cl = cl < 0 ? cl + W : cl;
+                cr = cr >= W ? cr - W : cr;
+            }
+            cl = cl < 0 ? 0 : (cl >= W ? W - 1 : cl);
+            cr = cr >= W ? W - 1 : cr;
+            px[0] = row[cl];
+            px[9] = row[cr];
+        };
+        auto store_x = [&](int r) {
+            bool rok = xvalid;
+            if (!circ) rok = rok && r >= 0 && r < H;
+            float v[10];
+#pragma unroll
+            for (int i = 0; i < 10; ++i) {
+                const int c = xc0 - 1 + i;        // image column (before wrapping)
+                const bool ok = rok && (circ || (c >= 0 && c < W)) && (c < x0 + ps + 1);
+                v[i] = ok ? px[i] : 0.f;
+            }
+            u32x4* slot = xs + ((r + 1) & 3) * WG_XSLOT + xg * WG_XP + xc;
+            const unsigned m12 = wpack2<PREC>(v[1], v[2]), m34 = wpack2<PREC>(v[3], v[4]);
+            const unsigned m56 = wpack2<PREC>(v[5], v[6]);
+            u32x4 u;
+            u[0] = wpack2<PREC>(v[0], v[1]); u[1] = wpack2<PREC>(v[2], v[3]);
+            u[2] = wpack2<PREC>(v[4], v[5]); u[3] = wpack2<PREC>(v[6], v[7]);
+            slot[0 * WG_NG * WG_XP] = u;                         // kx = 0: pixels p-1
+            u[0] = m12; u[1] = m34; u[2] = m56; u[3] = wpack2<PREC>(v[7], v[8]);
+            slot[1 * WG_NG * WG_XP] = u;                         // kx = 1: pixels p
+            u[0] = wpack2<PREC>(v[2], v[3]); u[1] = wpack2<PREC>(v[4], v[5]);
+            u[2] = wpack2<PREC>(v[6], v[7]); u[3] = wpack2<PREC>(v[8], v[9]);
+            slot[2 * WG_NG * WG_XP] = u;                         // kx = 2: pixels p+1
+        };
+        auto fetch_d = [&](int y) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                load8(dsrc[j] + (size_t)y * W, dc0, pd[j]);
+                load8(gsrc[j] + (size_t)y * W, dc0, pgv[j]);
+            }
+        };
+        auto store_d = [&](int y) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float v[8];
+                float s = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int c = dc0 + i;
+                    float t = pd[j][i];
+                    if (gated) t *= scm_act_grad_from_out(pgv[j][i], gate_act);
+                    v[i] = (dvalid[j] && c < x0 + ps) ? t : 0.f;
+                    s += v[i];
+                }
+                csum[j] += s;
+                u32x4 u;
+                u[0] = wpack2<PREC>(v[0], v[1]); u[1] = wpack2<PREC>(v[2], v[3]);
+                u[2] = wpack2<PREC>(v[4], v[5]); u[3] = wpack2<PREC>(v[6], v[7]);
+                dsm[(y & 1) * WG_DSTAGE + dg * WG_DP + (tid >> 3) + 64 * j] = u;
+            }
+        };
+
+        // prologue: x rows y_begin-1 and y_begin
+        __syncthreads();                         // the previous segment's MFMAs are done with the slots
+        fetch_x(y_begin - 1);
+        store_x(y_begin - 1);
+        fetch_x(y_begin);
+        store_x(y_begin);
+        fetch_x(y_begin + 1);
+        fetch_d(y_begin);
+
+        for (int y = y_begin; y < y_end; ++y) {
+            store_x(y + 1);
+            store_d(y);
+            __syncthreads();
+            if (y + 1 < y_end) {
+                fetch_x(y + 2);
+                fetch_d(y + 1);
+            }
+            const u32x4* dst = dsm + (y & 1) * WG_DSTAGE + wm * 32 + l31;
+            for (int ks = 0; ks < nks; ++ks) {
+                const int g = 2 * ks + lh;
+                const u32x4 av = dst[g * WG_DP];
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const u32x4* xr = xs + ((y + ky) & 3) * WG_XSLOT + g * WG_XP + wn * 32 + l31;
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx)
+                        acc[ky * 3 + kx] = wmfma<PREC>(av, xr[kx * WG_NG * WG_XP], acc[ky * 3 + kx]);
+                }
+            }
+        }
+    }
+
+    // ---- partial slab part[split][tap][co][ci]
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co_base + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int ci = ci_base + wn * 32 + l31;
+            if (co < a.cout && ci < cin) a.part[(((size_t)split * 9 + t) * a.cout + co) * cin + ci] = acc[t][r];
+        }
+    }
+    if (do_csum) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float s = csum[j];
+            s += __shfl_xor(s, 1);
+            s += __shfl_xor(s, 2);
+            s += __shfl_xor(s, 4);
+            const int co = co_base + (tid >> 3) + 64 * j;
+            if (dg == 0 && co < a.cout) a.csum_part[(size_t)split * a.cout + co] = s;
+        }
+    }
+}
+
+template <int PREC, bool VEC>
+static int launch_wgrad_h16(const WgradKArgs& a, const WgradPlan& p, hipStream_t s) {
+    const size_t lds = ((size_t)4 * WG_XSLOT + 2 * WG_DSTAGE) * 16;
+    auto kern = conv3x3_wgrad_h16_kernel<PREC, VEC>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        int rc = scm_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+                               "hipFuncSetAttribute");
+        if (rc) return rc;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.nsplit, p.co_groups * p.ci_groups), dim3(512), lds, s, a);
+    SCM_LAUNCH_CHECK("conv3x3_wgrad_h16_kernel");
+    return SCM_OK;
+}
+
+int scm_launch_wgrad_h16(const WgradKArgs& a, const WgradPlan& p, int precision, hipStream_t s) {
+    if (a.PS > 64 || a.W < 8) {
+        scm_set_error("scm_conv3x3_wgrad_h16: row segment of %d pixels (W = %d) unsupported", a.PS, a.W);
+        return SCM_EUNSUPPORTED;
+    }
+    const bool vec = (a.W % 4 == 0) && (a.PS % 8 == 0) &&
+                     ((reinterpret_cast<size_t>(a.x1) | reinterpret_cast<size_t>(a.x2) | reinterpret_cast<size_t>(a.dy) |
+                       reinterpret_cast<size_t>(a.gate)) % 16 == 0);
+    if (precision == SCM_PREC_F16)
+        return vec ? launch_wgrad_h16<SCM_PREC_F16, true>(a, p, s) : launch_wgrad_h16<SCM_PREC_F16, false>(a, p, s);
+    return vec ? launch_wgrad_h16<SCM_PREC_BF16, true>(a, p, s) : launch_wgrad_h16<SCM_PREC_BF16, false>(a, p, s);
+}

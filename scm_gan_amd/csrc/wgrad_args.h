@@ -1,0 +1,20 @@
+// Kernel-argument block and work split shared by the weight-gradient kernels
+// (conv3x3_wgrad.hip, conv3x3_wgrad_h16.hip).
+#pragma once
+#include "common.h"
+
+struct WgradKArgs {
+    const float* x1; const float* x2; int c1; int c2;
+    const float* dy; const float* gate; int gate_act; int cout;
+    float* part; float* csum_part;
+    int B; int H; int W; int pad_mode;
+    int spi; int rows_per_split; int nseg; int PS;
+    int ci_groups;
+};
+
+struct WgradPlan {
+    int mt, nt, spi, rows_per_split, nseg, PS, co_groups, ci_groups, nsplit, m16;
+};
+
+// 128 co x 64 ci tiles on v_mfma_f32_32x32x16_{f16,bf16} (conv3x3_wgrad_h16.hip)
+int scm_launch_wgrad_h16(const WgradKArgs& a, const WgradPlan& p, int precision, hipStream_t s);

@@ -53,6 +53,9 @@ parser.add_argument('--enable-disentanglement-loss', action='store_true', help='
 parser.add_argument('--counterfactual-horizon', type=int, default=1, help='Forward horizon for CF generation')
 # additions of this build
 parser.add_argument('--seed', type=int, default=0, help='Seed of weights, data and the Philox latent noise')
+parser.add_argument('--precision', choices=('fp32', 'fp16'), default='fp32',
+                    help="MFMA operand precision of the 3x3 convs: fp32 = the reference's arithmetic; fp16 = fp16 forward / "
+                         "bf16 gradient operands with fp32 accumulation (not in the reference)")
 parser.add_argument('--eval-every', type=int, default=2000, help='Evaluate + checkpoint cadence (ITERS_PER_VIDEO)')
 parser.add_argument('--log-every', type=int, default=10)
 
@@ -426,6 +429,7 @@ def main(argv=None):
     """main.py:64-103."""
     global args
     args = parser.parse_args(argv)
+    ops.set_compute_precision(args.precision)
     torch.manual_seed(args.seed)
     latent_dim = 16
     datasource = allocate_datasource(args.env, seed=args.seed)

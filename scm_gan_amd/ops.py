@@ -48,16 +48,43 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# ------------------------------------------------------------- precision
+# MFMA operand precision of the 3x3 same-size convolutions.  "fp32" (default, the
+# reference's arithmetic) or "fp16": forward on fp16 operands, gradient convolutions on
+# bf16 operands, both with fp32 accumulation over the same fp32 tensors
+# (scm_conv3x3_h16; BASELINE config 5 / SURVEY.md 8(d)).  Opt-in: parity claims and the
+# headline benchmark are fp32.
+PREC_F32, PREC_F16, PREC_BF16 = L.PREC_F32, L.PREC_F16, L.PREC_BF16
+_precision = ["fp32"]
+
+
+def compute_precision():
+    return _precision[0]
+
+
+def set_compute_precision(name):
+    if name not in ("fp32", "fp16"):
+        raise ValueError("compute precision must be 'fp32' or 'fp16', got %r" % (name,))
+    _precision[0] = name
+
+
 # ------------------------------------------------------------------ packs
 def pack_conv3x3(weight, cin, cout, transposed=False, cin_total=0, ci0=0):
-    """Weight packs (forward, dgrad) for scm_conv3x3 from a torch-layout weight."""
+    """Weight packs for scm_conv3x3 / scm_conv3x3_h16 from a torch-layout weight, in the
+    current compute precision: (forward pack, dgrad pack, forward prec, dgrad prec)."""
     lib = L.lib()
     w = _chk(weight.detach(), "pack_conv3x3")
+    if _precision[0] == "fp16":
+        fp = torch.empty(lib.scm_conv3x3_pack_h16_bytes(cin, cout) // 2, device=w.device, dtype=torch.int16)
+        dp = torch.empty(lib.scm_conv3x3_pack_h16_bytes(cout, cin) // 2, device=w.device, dtype=torch.int16)
+        L.check(lib.scm_pack_conv3x3_weights_h16(_p(w), cin, cout, int(transposed), cin_total, ci0, _p(fp), PREC_F16,
+                                                 _p(dp), PREC_BF16, _stream()), "scm_pack_conv3x3_weights_h16")
+        return fp, dp, PREC_F16, PREC_BF16
     fp = _new(w, lib.scm_conv3x3_pack_floats(cin, cout))
     dp = _new(w, lib.scm_conv3x3_pack_floats(cout, cin))
     L.check(lib.scm_pack_conv3x3_weights(_p(w), cin, cout, int(transposed), cin_total, ci0, _p(fp), _p(dp), _stream()),
             "scm_pack_conv3x3_weights")
-    return fp, dp
+    return fp, dp, PREC_F32, PREC_F32
 
 
 class KernelTimer(object):
@@ -86,13 +113,15 @@ class KernelTimer(object):
 kernel_timer = None     # set to a KernelTimer() to time the MFMA conv launches
 
 
-def conv_kernel_name(cout):
+def conv_kernel_name(cout, prec=0):
+    if prec:
+        return "conv3x3_h16_kernel<%s>" % ("f16" if prec == PREC_F16 else "bf16")
     if cout <= 16:
         return "conv3x3_m16_kernel"
     return "conv3x3_mfma_kernel<%s>" % ("4,2|4,4" if cout > 64 else ("2,4" if cout > 32 else "1,8"))
 
 
-def _conv3x3_raw(x1, x2, gate1, gate2, gate_act, wpack, cout, scale, bias, sbias, co1, pad, act):
+def _conv3x3_raw(x1, x2, gate1, gate2, gate_act, wpack, cout, scale, bias, sbias, co1, pad, act, prec=0):
     lib = L.lib()
     B, c1, H, W = x1.shape
     c2 = 0 if x2 is None else x2.shape[1]
@@ -101,9 +130,12 @@ def _conv3x3_raw(x1, x2, gate1, gate2, gate_act, wpack, cout, scale, bias, sbias
     d = L.ConvDesc(_p(x1), _p(x2), c1, c2, _p(gate1), _p(gate2), gate_act, _p(wpack), cout, _p(scale), _p(bias),
                    _p(sbias), _p(y1), _p(y2), co1, B, H, W, pad, act)
     if kernel_timer is not None:
-        ev = kernel_timer.bracket(conv_kernel_name(cout), 2.0 * B * H * W * cout * (c1 + c2) * 9)
+        ev = kernel_timer.bracket(conv_kernel_name(cout, prec), 2.0 * B * H * W * cout * (c1 + c2) * 9)
         ev[0].record()
-    L.check(lib.scm_conv3x3(ctypes.byref(d), _stream()), "scm_conv3x3")
+    if prec:
+        L.check(lib.scm_conv3x3_h16(ctypes.byref(d), prec, _stream()), "scm_conv3x3_h16")
+    else:
+        L.check(lib.scm_conv3x3(ctypes.byref(d), _stream()), "scm_conv3x3")
     if kernel_timer is not None:
         ev[1].record()
     return y1, y2
@@ -188,7 +220,7 @@ class Conv3x3Fn(Function):
         c2 = 0 if x2 is None else x2.shape[1]
         cout = w.shape[1] if cfg["transposed"] else w.shape[0]
         cin_total = w.shape[0] if cfg["transposed"] else w.shape[1]
-        fpack, dpack = cfg["packs"]
+        fpack, dpack, fprec, dprec = cfg["packs"]
         sbias = None
         if act_vec is not None:
             A = act_vec.shape[1]
@@ -196,8 +228,10 @@ class Conv3x3Fn(Function):
             sbias = _new(x1, B, cout)
             L.check(lib.scm_action_bias(_p(act_vec), _p(w), _p(inv_sigma), B, A, cout, cin_total, c1 + c2, _p(sbias),
                                         _stream()), "scm_action_bias")
-        y, _ = _conv3x3_raw(x1, x2, None, None, 0, fpack, cout, inv_sigma, bias, sbias, cout, cfg["pad"], cfg["act"])
+        y, _ = _conv3x3_raw(x1, x2, None, None, 0, fpack, cout, inv_sigma, bias, sbias, cout, cfg["pad"], cfg["act"],
+                            fprec)
         ctx.cfg = cfg
+        ctx.dprec = dprec
         ctx.shape = (B, c1, c2, H, W, cout, cin_total)
         ctx.has = (x2 is not None, act_vec is not None, bias is not None, inv_sigma is not None)
         ctx.params = (weight, bias)          # the Parameter objects: their .grad is looked up at backward time
@@ -216,7 +250,7 @@ class Conv3x3Fn(Function):
         dx1 = dx2 = d_act = dw = db = None
         if need_x1 or need_x2:
             dx1, dx2 = _conv3x3_raw(gy, None, y if act else None, None, act, dpack, c1 + c2, inv_sigma, None, None, c1,
-                                    cfg["pad"], ACT_NONE)
+                                    cfg["pad"], ACT_NONE, ctx.dprec)
         if need_w or need_b or need_a:
             pf, cf = ctypes.c_size_t(), ctypes.c_size_t()
             L.check(lib.scm_conv3x3_wgrad_workspace(B, H, W, c1 + c2, cout, ctypes.byref(pf), ctypes.byref(cf)),
@@ -239,7 +273,10 @@ class Conv3x3Fn(Function):
             d = L.WgradDesc(_p(x1), _p(x2), c1, c2, _p(gy), _p(y) if act else None, act, cout, _p(dw_eff), _p(db),
                             _p(csum), _p(part), _p(cws), B, H, W, cfg["pad"], int(cfg["transposed"]), acc_flag,
                             cin_total, 0, _p(w) if dot_part is not None else None, _p(dot_part))
-            L.check(lib.scm_conv3x3_wgrad(ctypes.byref(d), _stream()), "scm_conv3x3_wgrad")
+            if ctx.dprec:
+                L.check(lib.scm_conv3x3_wgrad_h16(ctypes.byref(d), ctx.dprec, _stream()), "scm_conv3x3_wgrad_h16")
+            else:
+                L.check(lib.scm_conv3x3_wgrad(ctypes.byref(d), _stream()), "scm_conv3x3_wgrad")
             if has_act:
                 A = act_vec.shape[1]
                 d_act = _new(gy, B, A)

@@ -215,3 +215,40 @@ def test_excitation_backtrack_runs_and_attributes():
     assert len(out["action_attributions"]) == 1 and out["action_attributions"][0].shape == (1, 4)
     m = out["latent_masks"][0]
     assert m.shape == z.shape and float(m.max()) <= 1.0 and torch.isfinite(m).all()
+
+
+def test_graphed_planner_matches_eager_and_is_faster():
+    """planner.GraphedRollout: the HIP-graph replay of compute_rollout_reward equals the eager
+    rollout started from the same SpectralNorm state, call after call."""
+    import copy
+    import time
+    from scm_gan_amd import main as T
+    from scm_gan_amd.planner import GraphedRollout
+    enc, dec, rp, disc, tr = build(110)
+    T.test_mode([tr, rp])
+    tr2, rp2 = copy.deepcopy(tr), copy.deepcopy(rp)
+    rng = np.random.default_rng(4)
+    zs = [dev((rng.random((1, 16, 32, 32)) < 0.5).astype(np.float32)) for _ in range(3)]
+    planner = GraphedRollout(tr, rp, 5)
+    # the graph's two warm-up rollouts + capture advance u/v: replay the same number of eager rollouts on the twin
+    with torch.no_grad():
+        got0 = planner(zs[0])
+        for _ in range(3):
+            T.compute_rollout_reward(zs[0], tr2, rp2, 5, selected_action=0)
+        for z in zs:
+            want = T.compute_rollout_reward(z, tr2, rp2, 5, selected_action=0)
+            got = planner(z)
+            assert abs(float(got) - float(want)) < 2e-3 * max(1.0, abs(float(want))), (float(got), float(want))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            planner(zs[0])
+        torch.cuda.synchronize()
+        t_graph = (time.perf_counter() - t0) / 5
+        t0 = time.perf_counter()
+        for _ in range(5):
+            T.compute_rollout_reward(zs[0], tr2, rp2, 5, selected_action=0)
+        torch.cuda.synchronize()
+        t_eager = (time.perf_counter() - t0) / 5
+    print("planner: graph %.2f ms  eager %.2f ms" % (t_graph * 1e3, t_eager * 1e3))
+    assert t_graph < t_eager

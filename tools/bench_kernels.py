@@ -19,7 +19,7 @@ def case(B, c1, c2, cout, H=64, W=64, which=('fwd', 'dgrad', 'wgrad'), n=10):
     cin = c1 + c2
     x1 = torch.randn(B, c1, H, W, device=dev); x2 = torch.randn(B, c2, H, W, device=dev) if c2 else None
     w = torch.randn(cout, cin, 3, 3, device=dev) * 0.05; b = torch.zeros(cout, device=dev)
-    fp, dp = ops.pack_conv3x3(w, cin, cout)
+    fp, dp = ops.pack_conv3x3(w, cin, cout)[:2]
     y = torch.empty(B, cout, H, W, device=dev); dy = torch.randn(B, cout, H, W, device=dev)
     dx1 = torch.empty(B, c1, H, W, device=dev); dx2 = torch.empty(B, c2, H, W, device=dev) if c2 else None
     fl = 2.0 * B * H * W * cout * cin * 9

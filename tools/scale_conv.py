@@ -5,7 +5,7 @@ dev = 'cuda'
 def run(B, cin, cout=128, H=64, W=64, act=1, n=8):
     x = torch.randn(B, cin, H, W, device=dev); w = torch.randn(cout, cin, 3, 3, device=dev) * 0.05
     b = torch.zeros(cout, device=dev)
-    fp, dp = ops.pack_conv3x3(w, cin, cout)
+    fp, dp = ops.pack_conv3x3(w, cin, cout)[:2]
     for _ in range(3): ops._conv3x3_raw(x, None, None, None, 0, fp, cout, None, b, None, cout, 1, act)
     torch.cuda.synchronize(); t0 = time.time()
     for _ in range(n): ops._conv3x3_raw(x, None, None, None, 0, fp, cout, None, b, None, cout, 1, act)
