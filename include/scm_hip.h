@@ -151,7 +151,7 @@ int scm_pack_conv3x3_weights_h16(const float* w, int cin, int cout, int transpos
                                  void* stream);
 int scm_conv3x3_h16(const scm_conv3x3_desc* d, int precision, void* stream);
 
-/* scm_conv3x3_wgrad with the 128 co x 64 ci workgroup tiles (cout > 64, cin > 32) on 16-bit
+/* scm_conv3x3_wgrad with the 128 co x 64 (32) ci workgroup tiles (cout > 64, cin > 16) on 16-bit
  * operands (dyp and x rounded to `precision` while staged; fp32 accumulation, fp32 partial slabs,
  * the same fixed-order reduction, workspaces as scm_conv3x3_wgrad_workspace).  Other shapes
  * run the fp32 kernels. */

@@ -383,6 +383,16 @@ static int launch_conv(const ConvKArgs& k, int groups, hipStream_t s) {
     if (rows > a.H) rows = a.H;
     a.plane = (rows + 2) * (a.W + 2);
     const bool gated = a.gate_act != 0;
+    if constexpr (CT == 4 && PT == 1) {
+        // 128-pixel tiles for grids that would leave CUs idle at 256 pixels (small batches:
+        // the planner's 25 beams, BASELINE configs[0] B = 8)
+        if (a.plane <= 1 * 256)
+            return gated ? launch_conv_nj<4, 1, 1, true, 2>(a, groups, s) : launch_conv_nj<4, 1, 1, false, 2>(a, groups, s);
+        if (a.plane <= 2 * 256)
+            return gated ? launch_conv_nj<4, 1, 2, true, 2>(a, groups, s) : launch_conv_nj<4, 1, 2, false, 2>(a, groups, s);
+        scm_set_error("scm_conv3x3: 128-pixel variant needs a halo tile <= 512 elements");
+        return SCM_EUNSUPPORTED;
+    }
     if constexpr (CT == 4 && PT == 2) {
         if (a.plane <= 2 * 256)
             return gated ? launch_conv_nj<4, 2, 2, true, 2>(a, groups, s) : launch_conv_nj<4, 2, 2, false, 2>(a, groups, s);
@@ -433,7 +443,15 @@ extern "C" int scm_conv3x3(const scm_conv3x3_desc* d, void* stream) {
         static const int one_wg = getenv("SCM_CONV_1WG") ? atoi(getenv("SCM_CONV_1WG")) : 0;
         int rows = (256 % d->W == 0) ? 256 / d->W : (256 + d->W - 2) / d->W + 1;
         if (rows > d->H) rows = d->H;
-        if (!one_wg && (rows + 2) * (d->W + 2) <= 768) return launch_conv<4, 2>(k, groups, s);
+        if (!one_wg && (rows + 2) * (d->W + 2) <= 768) {
+            // fewer 256-pixel workgroups than the chip holds at two per CU: halve the tile
+            static const int no_small = getenv("SCM_CONV_NO128") ? atoi(getenv("SCM_CONV_NO128")) : 0;
+            const long wgs = (long)d->B * ((d->H * d->W + 255) / 256) * groups;
+            int rows1 = (128 % d->W == 0) ? 128 / d->W : (128 + d->W - 2) / d->W + 1;
+            if (rows1 > d->H) rows1 = d->H;
+            if (!no_small && wgs < 512 && (rows1 + 2) * (d->W + 2) <= 512) return launch_conv<4, 1>(k, groups, s);
+            return launch_conv<4, 2>(k, groups, s);
+        }
         return launch_conv<4, 4>(k, groups, s);
     }
     if (ct == 2) return launch_conv<2, 4>(k, groups, s);

@@ -603,7 +603,12 @@ static int wgrad_impl(const scm_conv3x3_wgrad_desc* d, int precision, void* stre
     a.ci_groups = p.ci_groups;
     hipStream_t s = (hipStream_t)stream;
     int rc;
-    if (p.m16) {
+    if (precision != SCM_PREC_F32 && d->cout > 64 && p.m16 == 0 && p.mt == 4) {
+        // 128 co x 64 (32) ci tiles on the 16-bit MFMA (conv3x3_wgrad_h16.hip); same split, same slabs.
+        // cin <= 16 (Transition.conv1) stays on the fp32 kernel: that launch is bound by reading dy,
+        // 16-bit operands gain nothing there (106 vs 109 us) and cost gradient accuracy.
+        rc = scm_launch_wgrad_h16(a, p, precision, s);
+    } else if (p.m16) {
         const int nci = p.m16 == 1 ? 128 : 16, nco = p.m16 == 1 ? 16 : 128;
         const int PSP = a.PS + 6, XPL = (3 * PSP) | 1, DPL = (a.PS + 4) | 1;
         const size_t lds = ((size_t)nci * XPL + (size_t)nco * DPL) * sizeof(float);
@@ -619,8 +624,6 @@ static int wgrad_impl(const scm_conv3x3_wgrad_desc* d, int precision, void* stre
         hipLaunchKernelGGL(kern, dim3(p.nsplit, p.co_groups * p.ci_groups), dim3(512), lds, s, a);
         SCM_LAUNCH_CHECK("conv3x3_wgrad_m16_kernel");
         rc = SCM_OK;
-    } else if (precision != SCM_PREC_F32 && p.mt == 4 && p.nt == 2) {
-        rc = scm_launch_wgrad_h16(a, p, precision, s);      // 128 co x 64 ci tiles on the 16-bit MFMA (conv3x3_wgrad_h16.hip)
     } else if (p.mt == 4) rc = p.nt == 2 ? launch_wgrad<4, 2, 1>(a, p, s) : launch_wgrad<4, 1, 1>(a, p, s);
     else if (p.mt == 2) rc = p.nt == 4 ? launch_wgrad<2, 4, 1>(a, p, s) : launch_wgrad<2, 2, 1>(a, p, s);
     else rc = launch_wgrad<1, 4, 1>(a, p, s);

@@ -19,6 +19,7 @@
 // image: x rows in 4 rolling LDS slots (one new row per step), the dyp row double
 // buffered, one barrier per row.  The kernel is HBM-bound (x + dy + gate are read
 // once per ci group), the MFMAs take about a third of its time.
+#include <type_traits>
 #include "wgrad_args.h"
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -47,15 +48,19 @@ __device__ __forceinline__ f32x16 wmfma(u32x4 a, u32x4 b, f32x16 c) {
 }
 
 #define WG_NG 8                    // 8-pixel groups per row segment (PS <= 64)
-#define WG_XP 65                   // ci pitch of an x image (units): 8 lanes x stride 65 units hit 8 different bank quads
-#define WG_DP 129                  // co pitch of the dyp image
-#define WG_XSLOT (3 * WG_NG * WG_XP)   // units per x row slot: [kx][g][ci]
-#define WG_DSTAGE (WG_NG * WG_DP)      // units per dyp stage: [g][co]
+#define WG_DP 129                  // co pitch of the dyp image (units): 8 lanes x stride 129 units hit 8 different bank quads
+#define WG_DSTAGE (WG_NG * WG_DP)  // units per dyp stage: [g][co]
 
-// VEC: W % 4 == 0 and PS % 8 == 0 -> every 8-pixel group is two aligned float4 loads
-template <int PREC, bool VEC>
-__global__ void __launch_bounds__(512, 1) conv3x3_wgrad_h16_kernel(const WgradKArgs a) {
+// WN = ci tiles (of 32) per workgroup: 2 -> 8 waves, 128 co x 64 ci; 1 -> 4 waves, 128 co x 32 ci
+// (layers with cin <= 32).  VEC: W % 4 == 0 and PS % 8 == 0 -> every 8-pixel group is two aligned
+// float4 loads.
+template <int PREC, bool VEC, int WN>
+__global__ void __launch_bounds__(256 * WN, 1) conv3x3_wgrad_h16_kernel(const WgradKArgs a) {
     extern __shared__ __attribute__((aligned(16))) u32x4 wsm[];
+    constexpr int WG_XP = WN * 32 + 1;             // ci pitch of an x image
+    constexpr int WG_XSLOT = 3 * WG_NG * WG_XP;    // units per x row slot: [kx][g][ci]
+    constexpr int DT = 4 / WN;                     // dyp tasks per thread (128 co x 8 groups over 256*WN threads)
+    constexpr int DSTEP = 32 * WN;                 // co stride between a thread's dyp tasks
     u32x4* xs = wsm;                         // [4 slots][3][WG_NG][WG_XP]
     u32x4* dsm = wsm + 4 * WG_XSLOT;         // [2][WG_NG][WG_DP]
 
@@ -63,7 +68,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3_wgrad_h16_kernel(const WgradKA
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lh = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int W = a.W, H = a.H, HW = H * W;
     const int PS = a.PS;
 
@@ -75,7 +80,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3_wgrad_h16_kernel(const WgradKA
     if (y_end > H) y_end = H;
     const int cig = blockIdx.y % a.ci_groups;
     const int cog = blockIdx.y / a.ci_groups;
-    const int co_base = cog * 128, ci_base = cig * 64;
+    const int co_base = cog * 128, ci_base = cig * (WN * 32);
     const int cin = a.c1 + a.c2;
     const bool circ = a.pad_mode == SCM_PAD_CIRCULAR;
     const int gate_act = a.gate_act;
@@ -94,24 +99,26 @@ __global__ void __launch_bounds__(512, 1) conv3x3_wgrad_h16_kernel(const WgradKA
     const bool xvalid = xci < cin;
     const int xcc = xvalid ? xci : 0;
     const float* xsrc = xcc < a.c1 ? a.x1 + ((size_t)b * a.c1 + xcc) * HW : a.x2 + ((size_t)b * a.c2 + (xcc - a.c1)) * HW;
-    // dyp: two tasks per thread: channel dc = (tid >> 3) + 64 j, group dg = tid & 7
+    // dyp: DT tasks per thread: channel dc = (tid >> 3) + DSTEP j, group dg = tid & 7
     const int dg = tid & 7;
-    const float* dsrc[2];
-    const float* gsrc[2];
-    bool dvalid[2];
+    const float* dsrc[DT];
+    const float* gsrc[DT];
+    bool dvalid[DT];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int co = co_base + (tid >> 3) + 64 * j;
+    for (int j = 0; j < DT; ++j) {
+        const int co = co_base + (tid >> 3) + DSTEP * j;
         dvalid[j] = co < a.cout;
         const size_t o = ((size_t)b * a.cout + (dvalid[j] ? co : 0)) * HW;
         dsrc[j] = a.dy + o;
         gsrc[j] = (gated ? a.gate : a.dy) + o;
     }
-    float csum[2] = {0.f, 0.f};
+    float csum[DT];
+#pragma unroll
+    for (int j = 0; j < DT; ++j) csum[j] = 0.f;
     const bool do_csum = a.csum_part != nullptr && cig == 0;
 
     float px[10];                 // pixels p0-1 .. p0+8 of the x row
-    float pd[2][8], pgv[2][8];
+    float pd[DT][8], pgv[DT][8];
 
     for (int seg = 0; seg < a.nseg; ++seg) {
         const int x0 = seg * PS;
@@ -180,14 +187,14 @@ __global__ void __launch_bounds__(512, 1) conv3x3_wgrad_h16_kernel(const WgradKA
         };
         auto fetch_d = [&](int y) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < DT; ++j) {
                 load8(dsrc[j] + (size_t)y * W, dc0, pd[j]);
                 load8(gsrc[j] + (size_t)y * W, dc0, pgv[j]);
             }
         };
         auto store_d = [&](int y) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < DT; ++j) {
                 float v[8];
                 float s = 0.f;
 #pragma unroll
@@ -202,11 +209,14 @@ __global__ void __launch_bounds__(512, 1) conv3x3_wgrad_h16_kernel(const WgradKA
                 u32x4 u;
                 u[0] = wpack2<PREC>(v[0], v[1]); u[1] = wpack2<PREC>(v[2], v[3]);
                 u[2] = wpack2<PREC>(v[4], v[5]); u[3] = wpack2<PREC>(v[6], v[7]);
-                dsm[(y & 1) * WG_DSTAGE + dg * WG_DP + (tid >> 3) + 64 * j] = u;
+                dsm[(y & 1) * WG_DSTAGE + dg * WG_DP + (tid >> 3) + DSTEP * j] = u;
             }
         };
 
         // prologue: x rows y_begin-1 and y_begin
+        // (issuing the loads two row steps ahead from a second register set was measured: no gain
+        // with 4 waves, and with 8 waves the second set spills.  What bounds the kernel is that a
+        // row step reads one 256-byte image row from each of ~300 channel planes.)
         __syncthreads();                         // the previous segment's MFMAs are done with the slots
         fetch_x(y_begin - 1);
         store_x(y_begin - 1);
@@ -250,21 +260,21 @@ __global__ void __launch_bounds__(512, 1) conv3x3_wgrad_h16_kernel(const WgradKA
     }
     if (do_csum) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < DT; ++j) {
             float s = csum[j];
             s += __shfl_xor(s, 1);
             s += __shfl_xor(s, 2);
             s += __shfl_xor(s, 4);
-            const int co = co_base + (tid >> 3) + 64 * j;
+            const int co = co_base + (tid >> 3) + DSTEP * j;
             if (dg == 0 && co < a.cout) a.csum_part[(size_t)split * a.cout + co] = s;
         }
     }
 }
 
-template <int PREC, bool VEC>
+template <int PREC, bool VEC, int WN>
 static int launch_wgrad_h16(const WgradKArgs& a, const WgradPlan& p, hipStream_t s) {
-    const size_t lds = ((size_t)4 * WG_XSLOT + 2 * WG_DSTAGE) * 16;
-    auto kern = conv3x3_wgrad_h16_kernel<PREC, VEC>;
+    const size_t lds = ((size_t)4 * 3 * WG_NG * (WN * 32 + 1) + 2 * WG_DSTAGE) * 16;
+    auto kern = conv3x3_wgrad_h16_kernel<PREC, VEC, WN>;
     static bool attr_set = false;
     if (!attr_set) {
         int rc = scm_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -273,7 +283,7 @@ static int launch_wgrad_h16(const WgradKArgs& a, const WgradPlan& p, hipStream_t
         if (rc) return rc;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(p.nsplit, p.co_groups * p.ci_groups), dim3(512), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(p.nsplit, p.co_groups * p.ci_groups), dim3(256 * WN), lds, s, a);
     SCM_LAUNCH_CHECK("conv3x3_wgrad_h16_kernel");
     return SCM_OK;
 }
@@ -286,7 +296,11 @@ int scm_launch_wgrad_h16(const WgradKArgs& a, const WgradPlan& p, int precision,
     const bool vec = (a.W % 4 == 0) && (a.PS % 8 == 0) &&
                      ((reinterpret_cast<size_t>(a.x1) | reinterpret_cast<size_t>(a.x2) | reinterpret_cast<size_t>(a.dy) |
                        reinterpret_cast<size_t>(a.gate)) % 16 == 0);
-    if (precision == SCM_PREC_F16)
-        return vec ? launch_wgrad_h16<SCM_PREC_F16, true>(a, p, s) : launch_wgrad_h16<SCM_PREC_F16, false>(a, p, s);
-    return vec ? launch_wgrad_h16<SCM_PREC_BF16, true>(a, p, s) : launch_wgrad_h16<SCM_PREC_BF16, false>(a, p, s);
+    const bool narrow = p.ci_groups == 1 && a.c1 + a.c2 <= 32;      // one ci tile: 4 waves
+    if (precision == SCM_PREC_F16) {
+        if (narrow) return vec ? launch_wgrad_h16<SCM_PREC_F16, true, 1>(a, p, s) : launch_wgrad_h16<SCM_PREC_F16, false, 1>(a, p, s);
+        return vec ? launch_wgrad_h16<SCM_PREC_F16, true, 2>(a, p, s) : launch_wgrad_h16<SCM_PREC_F16, false, 2>(a, p, s);
+    }
+    if (narrow) return vec ? launch_wgrad_h16<SCM_PREC_BF16, true, 1>(a, p, s) : launch_wgrad_h16<SCM_PREC_BF16, false, 1>(a, p, s);
+    return vec ? launch_wgrad_h16<SCM_PREC_BF16, true, 2>(a, p, s) : launch_wgrad_h16<SCM_PREC_BF16, false, 2>(a, p, s);
 }

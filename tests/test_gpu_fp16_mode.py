@@ -76,7 +76,8 @@ def test_conv_h16_exact_on_rounded_operands(B, c1, c2, cout, H, W, circ):
 
 @pytest.mark.parametrize("B,c1,c2,cout,H,W,circ,gate", [
     (2, 64, 0, 128, 16, 16, 1, 1), (3, 40, 30, 100, 20, 12, 0, 1), (2, 128, 128, 128, 64, 64, 1, 1),
-    (1, 64, 0, 128, 84, 84, 0, 0), (1, 48, 0, 128, 128, 128, 1, 2)])
+    (1, 64, 0, 128, 84, 84, 0, 0), (1, 48, 0, 128, 128, 128, 1, 2), (2, 24, 0, 128, 16, 16, 1, 1),
+    (3, 17, 0, 128, 20, 12, 0, 1), (2, 20, 5, 100, 64, 64, 1, 2)])
 def test_wgrad_h16_exact_on_rounded_operands(B, c1, c2, cout, H, W, circ, gate):
     from scm_gan_amd import _lib as L
     lib = L.lib()

@@ -118,6 +118,10 @@ def wcase(B, c1, c2, cout, H=64, W=64, circ=1, check=True, n=10, gate=1):
 
 if __name__ == '__main__' and 'w' in sys.argv[1:]:
     wcase(2, 64, 0, 128, 16, 16, 1)
+    wcase(2, 16, 0, 128, 16, 16, 1)
+    wcase(3, 9, 0, 128, 20, 12, 0)
+    wcase(2, 20, 5, 100, 64, 64, 1)
+    wcase(64, 16, 0, 128, check=False)
     wcase(3, 40, 30, 100, 20, 12, 0)
     wcase(2, 128, 128, 128, 64, 64, 1)
     wcase(1, 64, 0, 128, 84, 84, 0, gate=0)
