@@ -256,6 +256,49 @@ __global__ void __launch_bounds__(256, WPS) conv3x3_mfma_kernel(const ConvKArgs 
                 badd[m][r] += a.sbias[(size_t)b * a.cout + (co < a.cout ? co : a.cout - 1)];
             }
     }
+    if constexpr (PT <= 4 && CT >= 2) {
+        // cout > 32 variants (their LDS stage is larger than the four slabs): transpose each wave's 32-channel x NPW-pixel slab through its own
+        // LDS region and store float4s (whole row runs, a quarter of the store instructions; the
+        // lane -> pixel / register -> channel accumulator layout costs one store instruction per
+        // register otherwise).
+        constexpr int EP = NPW + 4;
+        float* ep = smem + wave * (32 * EP);
+        const bool vec = (HW & 3) == 0;
+        __syncthreads();                                // every wave is done reading the stage
+#pragma unroll
+        for (int m = 0; m < CT; ++m) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+#pragma unroll
+                for (int n = 0; n < PT; ++n) ep[row * EP + n * 32 + l31] = scm_act(acc[m][n][r] * sc + badd[m][r], a.act);
+            }
+            __syncthreads();
+            constexpr int Q4 = NPW / 4;                 // float4s per channel row of the slab
+            constexpr int RP = 64 / Q4;                 // rows per wave instruction
+#pragma unroll
+            for (int k = 0; k < 32 / RP; ++k) {
+                const int row = RP * k + lane / Q4;
+                const int q = lane % Q4;
+                const int co = cg * CW + m * 32 + row;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(ep + row * EP + 4 * q);
+                const int p = p0 + wave * NPW + 4 * q;
+                if (co < a.cout) {
+                    float* dst = (co < a.co1 ? a.y1 + ((size_t)b * a.co1 + co) * HW
+                                             : a.y2 + ((size_t)b * co2n + (co - a.co1)) * HW) + p;
+                    if (vec && p + 3 < HW) {
+                        *reinterpret_cast<f32x4*>(dst) = v;
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (p + i < HW) dst[i] = v[i];
+                    }
+                }
+            }
+            if (m + 1 < CT) __syncthreads();
+        }
+        return;
+    }
     const int pbase = p0 + wave * NPW + l31;
 #pragma unroll
     for (int m = 0; m < CT; ++m) {
