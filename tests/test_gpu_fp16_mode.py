@@ -190,3 +190,31 @@ def test_training_fp16_tracks_fp32(fp16_mode):
     assert np.all(np.isfinite(l16))
     assert np.max(np.abs(l16 - l32) / np.abs(l32)) < 5e-2, (l16, l32)
     assert l16[-1] < l16[0]
+
+
+def test_cfg5_shape_step_fp16(fp16_mode):
+    """BASELINE configs[4] shape (128x128x4 frames, 4 actions, 2 rewards; small batch/horizon here):
+    one optimizer step in the 16-bit mode against the fp32 path from the same state."""
+    from scm_gan_amd import main as T, models as M, ops
+    from scm_gan_amd.datasource import SyntheticDatasource
+
+    def run(mode):
+        ops.set_compute_precision(mode)
+        torch.manual_seed(11)
+        enc, dec, rp, disc, tr = M.Encoder(16, 4), M.Decoder(16, 4), M.RewardPredictor(16, 2), M.Discriminator(), \
+            M.Transition(16, 4)
+        tr.seed_noise(3)
+        opts = T.parser.parse_args(["--horizon-min", "4", "--horizon-max", "4", "--batch-size", "2"])
+        trainer = T.Trainer(16, 4, 2, enc, dec, rp, disc, tr, opts)
+        ds = SyntheticDatasource(seed=9, height=128, width=128, channels=4, num_actions=4, num_rewards=2)
+        s, r, d, a = ds.get_trajectories(2, 4)[:4]
+        loss = trainer.step(torch.as_tensor(s, dtype=torch.float32).cuda(), torch.as_tensor(r, dtype=torch.float32).cuda(),
+                            torch.as_tensor(d.astype(np.float32)).cuda(), T.onehot(a, 4), theta=0.5, train_iter=1)
+        w = torch.cat([p.detach().flatten() for p in list(tr.parameters()) + list(enc.parameters())])
+        return float(loss), w
+
+    l16, w16 = run("fp16")
+    l32, w32 = run("fp32")
+    assert abs(l16 - l32) / abs(l32) < 2e-2, (l16, l32)
+    # Adam's first step moves every weight by ~lr * sign(g): the two modes agree wherever the gradient sign does
+    assert float((w16 - w32).abs().max()) < 3e-3
