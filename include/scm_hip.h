@@ -81,6 +81,15 @@ typedef struct scm_conv3x3_desc {
     float* y1; float* y2; int32_t co1;
     int32_t B; int32_t H; int32_t W;
     int32_t pad_mode; int32_t act;
+    /* Optional 1-bit form of the leaky-relu gate (both may be NULL), words [B][ceil(C/32)][H*W],
+     * bit j of word w = "channel 32w+j of the activation output is > 0":
+     *   gate_mask_out : written by a forward call with act == SCM_ACT_LRELU and cout > 32
+     *                   (C = cout), next to y;
+     *   gate_mask_in  : read by a gradient call with gate_act == SCM_ACT_LRELU instead of
+     *                   gate1 (C = c1, c2 must be 0) by the kernels for cout > 16; others
+     *                   keep reading gate1, which must still be passed.
+     * A gradient convolution then loads one word per pixel and 32 channels instead of 32 floats. */
+    uint32_t* gate_mask_out; const uint32_t* gate_mask_in;
 } scm_conv3x3_desc;
 
 int scm_conv3x3(const scm_conv3x3_desc* d, void* stream);
@@ -128,6 +137,8 @@ typedef struct scm_conv3x3_wgrad_desc {
     int32_t dw_cin_total; int32_t dw_ci0;   /* dw holds dw_cin_total input channels (0 = c1+c2); write slice at dw_ci0 */
     const float* dot_w; float* dot_part;    /* optional: dot_part[i] = partial <dw, dot_w> of reduce block i
                                                (ceil(9*cout*cin/256) floats) for scm_sn_fold_grad */
+    const uint32_t* gate_mask;              /* optional 1-bit leaky-relu gate (scm_conv3x3_desc.gate_mask_out of the
+                                               forward call, C = cout); `gate` must still be passed */
 } scm_conv3x3_wgrad_desc;
 
 int scm_conv3x3_wgrad_workspace(int B, int H, int W, int cin, int cout, size_t* part_floats,

@@ -29,6 +29,7 @@ class ConvDesc(ctypes.Structure):
         ("y1", ctypes.c_void_p), ("y2", ctypes.c_void_p), ("co1", ctypes.c_int32),
         ("B", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32),
         ("pad_mode", ctypes.c_int32), ("act", ctypes.c_int32),
+        ("gate_mask_out", ctypes.c_void_p), ("gate_mask_in", ctypes.c_void_p),
     ]
 
 
@@ -43,6 +44,7 @@ class WgradDesc(ctypes.Structure):
         ("transposed_dst", ctypes.c_int32), ("accumulate", ctypes.c_int32),
         ("dw_cin_total", ctypes.c_int32), ("dw_ci0", ctypes.c_int32),
         ("dot_w", ctypes.c_void_p), ("dot_part", ctypes.c_void_p),
+        ("gate_mask", ctypes.c_void_p),
     ]
 
 

@@ -51,7 +51,8 @@ __device__ __forceinline__ f32x16 mfma_h16(u32x4 a, u32x4 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b16x8, a), __builtin_bit_cast(b16x8, b), c, 0, 0, 0);
 }
 
-template <int PREC, int CT, int PT, int NJ, bool GATED>
+// GATED: 0 plain input, 1 input * act'(gate tensor), 2 input * leaky-relu slope from the 1-bit gate mask
+template <int PREC, int CT, int PT, int NJ, int GATED>
 __global__ void __launch_bounds__(256, 1) conv3x3_h16_kernel(const ConvKArgs a) {
     extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
     constexpr int CW = CT * 32;
@@ -129,7 +130,9 @@ __global__ void __launch_bounds__(256, 1) conv3x3_h16_kernel(const ConvKArgs a) 
     const int gate_act = GATED ? a.gate_act : 0;
 
     unsigned pw[WR][4];
-    float px[HKC][NJ], pg[GATED ? HKC : 1][GATED ? NJ : 1];
+    float px[HKC][NJ], pg[GATED == 1 ? HKC : 1][GATED == 1 ? NJ : 1];
+    unsigned pm[GATED == 2 ? NJ : 1];
+    const int mask_nw = (a.c1 + 31) >> 5;
 
     auto fetch = [&](int ci0) {
 #pragma unroll
@@ -148,11 +151,17 @@ __global__ void __launch_bounds__(256, 1) conv3x3_h16_kernel(const ConvKArgs a) 
             const float* src = (first ? a.x1 : a.x2) + o;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) px[c][j] = src[goff[j]];
-            if constexpr (GATED) {
+            if constexpr (GATED == 1) {
                 const float* gsrc = (first ? a.gate1 : a.gate2) + o;
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) pg[c][j] = gsrc[goff[j]];
             }
+        }
+        if constexpr (GATED == 2) {
+            const int w = (ci0 < cin ? ci0 : 0) >> 5;
+            const unsigned* mrow = a.mask_in + ((size_t)b * mask_nw + w) * HW;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) pm[j] = mrow[goff[j]];
         }
     };
     auto store = [&](int ci0, int buf) {
@@ -174,7 +183,8 @@ __global__ void __launch_bounds__(256, 1) conv3x3_h16_kernel(const ConvKArgs a) 
                 for (int i = 0; i < 8; ++i) {
                     const int c = 8 * h + i;
                     float t = px[c][j];
-                    if constexpr (GATED) t *= scm_act_grad_from_out(pg[c][j], gate_act);
+                    if constexpr (GATED == 1) t *= scm_act_grad_from_out(pg[c][j], gate_act);
+                    if constexpr (GATED == 2) t *= ((pm[j] >> ((ci0 & 31) + c)) & 1u) ? 1.f : 0.01f;
                     v[i] = (ok && ci0 + c < cin) ? t : 0.f;
                 }
                 u32x4 u;
@@ -274,12 +284,15 @@ __global__ void __launch_bounds__(256, 1) conv3x3_h16_kernel(const ConvKArgs a) 
             for (int n = 0; n < PT; ++n) ep[row * EP + n * 32 + l31] = scm_act(acc[m][n][r] * sc + badd[m][r], a.act);
         }
         __syncthreads();
+        unsigned bits[4] = {0u, 0u, 0u, 0u};        // sign bits of this lane's rows, per pixel of its float4
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             const int row = 2 * k + lh;
             const int co = cg * CW + m * 32 + row;
             const f32x4 v = *reinterpret_cast<const f32x4*>(ep + row * EP + 4 * l31);
             const int p = p0 + wave * NPW + 4 * l31;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bits[i] |= (v[i] > 0.f ? 1u : 0u) << row;
             if (co < a.cout) {
                 float* dst = (co < a.co1 ? a.y1 + ((size_t)b * a.co1 + co) * HW
                                          : a.y2 + ((size_t)b * co2n + (co - a.co1)) * HW) + p;
@@ -289,6 +302,24 @@ __global__ void __launch_bounds__(256, 1) conv3x3_h16_kernel(const ConvKArgs a) 
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
                         if (p + i < HW) dst[i] = v[i];
+                }
+            }
+        }
+        if (a.mask_out) {                           // wave-uniform: the 1-bit leaky-relu gate of these 32 channels
+            const int p = p0 + wave * NPW + 4 * l31;
+            const int nw = (a.cout + 31) >> 5, w = cg * CT + m;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bits[i] |= __shfl_xor(bits[i], 32);
+            if (lh == 0 && w < nw) {
+                unsigned* dst = a.mask_out + ((size_t)b * nw + w) * HW + p;
+                if (vec && p + 3 < HW) {
+                    u32x4 t;
+                    t[0] = bits[0]; t[1] = bits[1]; t[2] = bits[2]; t[3] = bits[3];
+                    *reinterpret_cast<u32x4*>(dst) = t;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (p + i < HW) dst[i] = bits[i];
                 }
             }
         }
@@ -372,7 +403,7 @@ extern "C" int scm_pack_conv3x3_weights_h16(const float* w, int cin, int cout, i
 }
 
 // ------------------------------------------------------------------ launch
-template <int PREC, int CT, int NJ, bool GATED>
+template <int PREC, int CT, int NJ, int GATED>
 static int launch_h16_nj(const ConvKArgs& a, int groups, hipStream_t s) {
     constexpr int WR = (9 * 2 * CT * 32 + 255) / 256;
     constexpr size_t stage = ((size_t)WR * 256 + 2 * NJ * 256) * 16;
@@ -394,6 +425,13 @@ static int launch_h16_nj(const ConvKArgs& a, int groups, hipStream_t s) {
     return SCM_OK;
 }
 
+template <int PREC, int CT, int NJ>
+static int launch_h16_g(const ConvKArgs& a, int groups, hipStream_t s) {
+    if (a.gate_act == 0) return launch_h16_nj<PREC, CT, NJ, 0>(a, groups, s);
+    if (a.mask_in && a.gate_act == SCM_ACT_LRELU && a.c2 == 0) return launch_h16_nj<PREC, CT, NJ, 2>(a, groups, s);
+    return launch_h16_nj<PREC, CT, NJ, 1>(a, groups, s);
+}
+
 template <int PREC, int CT>
 static int launch_h16(const ConvKArgs& k, int groups, hipStream_t s) {
     constexpr int NP = 512;
@@ -403,13 +441,9 @@ static int launch_h16(const ConvKArgs& k, int groups, hipStream_t s) {
     int rows = (NP % a.W == 0) ? NP / a.W : (NP + a.W - 2) / a.W + 1;
     if (rows > a.H) rows = a.H;
     a.plane = (rows + 2) * (a.W + 2);
-    const bool gated = a.gate_act != 0;
-    if (a.plane <= 3 * 256)
-        return gated ? launch_h16_nj<PREC, CT, 3, true>(a, groups, s) : launch_h16_nj<PREC, CT, 3, false>(a, groups, s);
-    if (a.plane <= 4 * 256)
-        return gated ? launch_h16_nj<PREC, CT, 4, true>(a, groups, s) : launch_h16_nj<PREC, CT, 4, false>(a, groups, s);
-    if (a.plane <= 6 * 256)
-        return gated ? launch_h16_nj<PREC, CT, 6, true>(a, groups, s) : launch_h16_nj<PREC, CT, 6, false>(a, groups, s);
+    if (a.plane <= 3 * 256) return launch_h16_g<PREC, CT, 3>(a, groups, s);
+    if (a.plane <= 4 * 256) return launch_h16_g<PREC, CT, 4>(a, groups, s);
+    if (a.plane <= 6 * 256) return launch_h16_g<PREC, CT, 6>(a, groups, s);
     scm_set_error("scm_conv3x3_h16: image width %d too large for the halo staging map", a.W);
     return SCM_EUNSUPPORTED;
 }
@@ -446,6 +480,9 @@ extern "C" int scm_conv3x3_h16(const scm_conv3x3_desc* d, int precision, void* s
     k.y1 = d->y1; k.y2 = d->y2; k.co1 = d->co1;
     k.B = d->B; k.H = d->H; k.W = d->W; k.pad_mode = d->pad_mode; k.act = d->act;
     k.tiles_per_img = 0; k.plane = 0;
+    k.mask_in = d->gate_mask_in;
+    k.mask_out = (d->act == SCM_ACT_LRELU && d->cout > 32) ? d->gate_mask_out : nullptr;
+    SCM_REQUIRE(!d->gate_mask_out || k.mask_out, "scm_conv3x3_h16: gate_mask_out needs act == LRELU and cout > 32");
     hipStream_t s = (hipStream_t)stream;
     return precision == SCM_PREC_F16 ? launch_h16_ct<SCM_PREC_F16>(k, s) : launch_h16_ct<SCM_PREC_BF16>(k, s);
 }

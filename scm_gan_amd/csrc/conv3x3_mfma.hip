@@ -30,7 +30,11 @@
 //   issue the next chunk's global loads into registers | 36 x CT*PT MFMAs
 // Every global load is unconditional on a clamped address (a load under a
 // per-lane condition makes hipcc branch around it and serialise the loads).
-template <int CT, int PT, int NJ, bool GATED, int WPS = 1>
+typedef unsigned u32x4m __attribute__((ext_vector_type(4)));
+
+// GATED: 0 = plain input, 1 = input * act'(gate tensor), 2 = input * leaky-relu slope from the 1-bit
+// gate mask (one word per pixel and 32 channels instead of 32 floats).
+template <int CT, int PT, int NJ, int GATED, int WPS = 1>
 __global__ void __launch_bounds__(256, WPS) conv3x3_mfma_kernel(const ConvKArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int CW = CT * 32;
@@ -112,7 +116,9 @@ __global__ void __launch_bounds__(256, WPS) conv3x3_mfma_kernel(const ConvKArgs 
     const int gate_act = GATED ? a.gate_act : 0;
 
     float pw[WR][4];      // plain floats: an ext_vector array captured by the lambdas lands in scratch
-    float px[KC][NJ], pg[KC][NJ];
+    float px[KC][NJ], pg[GATED == 1 ? KC : 1][GATED == 1 ? NJ : 1];
+    unsigned pm[GATED == 2 ? NJ : 1];
+    const int mask_nw = (a.c1 + 31) >> 5;
 
     auto fetch = [&](int ci0) {
 #pragma unroll
@@ -131,11 +137,17 @@ __global__ void __launch_bounds__(256, WPS) conv3x3_mfma_kernel(const ConvKArgs 
             const float* src = (first ? a.x1 : a.x2) + o;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) px[c][j] = src[goff[j]];
-            if constexpr (GATED) {
+            if constexpr (GATED == 1) {
                 const float* gsrc = (first ? a.gate1 : a.gate2) + o;
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) pg[c][j] = gsrc[goff[j]];
             }
+        }
+        if constexpr (GATED == 2) {
+            const int w = (ci0 < cin ? ci0 : 0) >> 5;
+            const unsigned* mrow = a.mask_in + ((size_t)b * mask_nw + w) * HW;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) pm[j] = mrow[goff[j]];
         }
     };
     auto store = [&](int ci0, int buf) {
@@ -157,7 +169,8 @@ __global__ void __launch_bounds__(256, WPS) conv3x3_mfma_kernel(const ConvKArgs 
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 float v = px[c][j];
-                if constexpr (GATED) v *= scm_act_grad_from_out(pg[c][j], gate_act);
+                if constexpr (GATED == 1) v *= scm_act_grad_from_out(pg[c][j], gate_act);
+                if constexpr (GATED == 2) v *= ((pm[j] >> ((ci0 & 31) + c)) & 1u) ? 1.f : 0.01f;
                 xl[c * PLANE + tid + 256 * j] = (cvalid && (okmask & (1u << j))) ? v : 0.f;
             }
         }
@@ -276,6 +289,7 @@ __global__ void __launch_bounds__(256, WPS) conv3x3_mfma_kernel(const ConvKArgs 
             __syncthreads();
             constexpr int Q4 = NPW / 4;                 // float4s per channel row of the slab
             constexpr int RP = 64 / Q4;                 // rows per wave instruction
+            unsigned bits[4] = {0u, 0u, 0u, 0u};        // sign bits of this lane's rows, per pixel of its float4
 #pragma unroll
             for (int k = 0; k < 32 / RP; ++k) {
                 const int row = RP * k + lane / Q4;
@@ -283,6 +297,8 @@ __global__ void __launch_bounds__(256, WPS) conv3x3_mfma_kernel(const ConvKArgs 
                 const int co = cg * CW + m * 32 + row;
                 const f32x4 v = *reinterpret_cast<const f32x4*>(ep + row * EP + 4 * q);
                 const int p = p0 + wave * NPW + 4 * q;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bits[i] |= (v[i] > 0.f ? 1u : 0u) << row;
                 if (co < a.cout) {
                     float* dst = (co < a.co1 ? a.y1 + ((size_t)b * a.co1 + co) * HW
                                              : a.y2 + ((size_t)b * co2n + (co - a.co1)) * HW) + p;
@@ -292,6 +308,28 @@ __global__ void __launch_bounds__(256, WPS) conv3x3_mfma_kernel(const ConvKArgs 
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
                             if (p + i < HW) dst[i] = v[i];
+                    }
+                }
+            }
+            if (a.mask_out) {                           // wave-uniform: the 1-bit leaky-relu gate of these 32 channels
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int o = Q4; o < 64; o <<= 1) bits[i] |= __shfl_xor(bits[i], o);
+                }
+                const int q = lane % Q4;
+                const int p = p0 + wave * NPW + 4 * q;
+                const int nw = (a.cout + 31) >> 5, w = cg * CT + m;
+                if (lane < Q4 && w < nw) {
+                    unsigned* dst = a.mask_out + ((size_t)b * nw + w) * HW + p;
+                    if (vec && p + 3 < HW) {
+                        u32x4m t;
+                        t[0] = bits[0]; t[1] = bits[1]; t[2] = bits[2]; t[3] = bits[3];
+                        *reinterpret_cast<u32x4m*>(dst) = t;
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (p + i < HW) dst[i] = bits[i];
                     }
                 }
             }
@@ -393,7 +431,7 @@ extern "C" int scm_pack_conv3x3_weights(const float* w, int cin, int cout, int t
     return SCM_OK;
 }
 
-template <int CT, int PT, int NJ, bool GATED, int WPS = 1>
+template <int CT, int PT, int NJ, int GATED, int WPS = 1>
 static int launch_conv_nj(const ConvKArgs& a, int groups, hipStream_t s) {
     constexpr int W4 = KC * 9 * CT * 32 / 4, WR = (W4 + 255) / 256;
     const size_t lds = ((size_t)WR * 256 * 4 + (size_t)KC * NJ * 256) * sizeof(float) * ((NJ == 4 && WPS == 1) ? 2 : 1);
@@ -416,6 +454,16 @@ static int launch_conv_nj(const ConvKArgs& a, int groups, hipStream_t s) {
     return SCM_OK;
 }
 
+// gate mode of a launch: 0 none, 1 gate tensor, 2 1-bit mask (leaky-relu only)
+static inline int gate_mode(const ConvKArgs& a) {
+    if (a.gate_act == 0) return 0;
+    return (a.mask_in && a.gate_act == SCM_ACT_LRELU && a.c2 == 0) ? 2 : 1;
+}
+#define SCM_LAUNCH_G(CT_, PT_, NJ_, ...)                                                      \
+    (g == 2 ? launch_conv_nj<CT_, PT_, NJ_, 2, ##__VA_ARGS__>(a, groups, s)                   \
+            : (g == 1 ? launch_conv_nj<CT_, PT_, NJ_, 1, ##__VA_ARGS__>(a, groups, s)         \
+                      : launch_conv_nj<CT_, PT_, NJ_, 0, ##__VA_ARGS__>(a, groups, s)))
+
 template <int CT, int PT>
 static int launch_conv(const ConvKArgs& k, int groups, hipStream_t s) {
     constexpr int NP = 128 * PT;
@@ -425,30 +473,23 @@ static int launch_conv(const ConvKArgs& k, int groups, hipStream_t s) {
     int rows = (NP % a.W == 0) ? NP / a.W : (NP + a.W - 2) / a.W + 1;
     if (rows > a.H) rows = a.H;
     a.plane = (rows + 2) * (a.W + 2);
-    const bool gated = a.gate_act != 0;
+    const int g = gate_mode(a);
     if constexpr (CT == 4 && PT == 1) {
         // 128-pixel tiles for grids that would leave CUs idle at 256 pixels (small batches:
         // the planner's 25 beams, BASELINE configs[0] B = 8)
-        if (a.plane <= 1 * 256)
-            return gated ? launch_conv_nj<4, 1, 1, true, 2>(a, groups, s) : launch_conv_nj<4, 1, 1, false, 2>(a, groups, s);
-        if (a.plane <= 2 * 256)
-            return gated ? launch_conv_nj<4, 1, 2, true, 2>(a, groups, s) : launch_conv_nj<4, 1, 2, false, 2>(a, groups, s);
+        if (a.plane <= 1 * 256) return SCM_LAUNCH_G(4, 1, 1, 2);
+        if (a.plane <= 2 * 256) return SCM_LAUNCH_G(4, 1, 2, 2);
         scm_set_error("scm_conv3x3: 128-pixel variant needs a halo tile <= 512 elements");
         return SCM_EUNSUPPORTED;
     }
     if constexpr (CT == 4 && PT == 2) {
-        if (a.plane <= 2 * 256)
-            return gated ? launch_conv_nj<4, 2, 2, true, 2>(a, groups, s) : launch_conv_nj<4, 2, 2, false, 2>(a, groups, s);
-        if (a.plane <= 3 * 256)
-            return gated ? launch_conv_nj<4, 2, 3, true, 2>(a, groups, s) : launch_conv_nj<4, 2, 3, false, 2>(a, groups, s);
+        if (a.plane <= 2 * 256) return SCM_LAUNCH_G(4, 2, 2, 2);
+        if (a.plane <= 3 * 256) return SCM_LAUNCH_G(4, 2, 3, 2);
         scm_set_error("scm_conv3x3: 2-WG/CU variant needs a halo tile <= 768 elements");
         return SCM_EUNSUPPORTED;
     }
-    if (a.plane <= 4 * 256)
-        return gated ? launch_conv_nj<CT, PT, 4, true>(a, groups, s) : launch_conv_nj<CT, PT, 4, false>(a, groups, s);
-    if (a.plane <= MAXJ * 256)
-        return gated ? launch_conv_nj<CT, PT, MAXJ, true>(a, groups, s)
-                     : launch_conv_nj<CT, PT, MAXJ, false>(a, groups, s);
+    if (a.plane <= 4 * 256) return SCM_LAUNCH_G(CT, PT, 4);
+    if (a.plane <= MAXJ * 256) return SCM_LAUNCH_G(CT, PT, MAXJ);
     scm_set_error("scm_conv3x3: image width %d too large for the halo staging map", a.W);
     return SCM_EUNSUPPORTED;
 }
@@ -475,6 +516,9 @@ extern "C" int scm_conv3x3(const scm_conv3x3_desc* d, void* stream) {
     k.y1 = d->y1; k.y2 = d->y2; k.co1 = d->co1;
     k.B = d->B; k.H = d->H; k.W = d->W; k.pad_mode = d->pad_mode; k.act = d->act;
     k.tiles_per_img = 0; k.plane = 0;
+    k.mask_in = d->gate_mask_in;
+    k.mask_out = (d->act == SCM_ACT_LRELU && d->cout > 32) ? d->gate_mask_out : nullptr;
+    SCM_REQUIRE(!d->gate_mask_out || k.mask_out, "scm_conv3x3: gate_mask_out needs act == LRELU and cout > 32");
     if (d->cout <= 16) return scm_launch_conv3x3_m16(k, (hipStream_t)stream);
     const int ct = conv_ct(d->cout);
     const int groups = (d->cout + ct * 32 - 1) / (ct * 32);

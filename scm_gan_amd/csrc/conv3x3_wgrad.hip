@@ -29,7 +29,9 @@
 //   barrier | registers -> LDS (x row y+1 into the rolling slot, dyp row y) |
 //   barrier | issue global loads of row y+1's data into registers | 288 MFMAs
 // so the HBM/L2 latency of the next row hides under this row's MFMAs.
-template <int WM, int WN, int NTW>
+// MASK: the leaky-relu gate comes from the 1-bit mask (one word per pixel for the wave's DR
+// channels) instead of DR gate floats per pixel.
+template <int WM, int WN, int NTW, bool MASK>
 __global__ void __launch_bounds__(WM * WN * 64, (WM * WN) / 4) conv3x3_wgrad_kernel(const WgradKArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves");
@@ -101,7 +103,10 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN) / 4) conv3x3_wgrad_ker
     const float* hsrc = xbase(hc < NT * 32 ? hc : 0, hvalid);
     hvalid = hvalid && hc < NT * 32;
 
-    float pdy[DR], pg[DR], px[XR], phalo = 0.f;
+    float pdy[DR], pg[MASK ? 1 : DR], px[XR], phalo = 0.f;
+    unsigned pmask = 0u;
+    static_assert(!MASK || 32 % DR == 0, "a wave's dy channels must not straddle mask words");
+    const int mask_nw = (a.cout + 31) >> 5;
 
     for (int seg = 0; seg < a.nseg; ++seg) {
         const int x0 = seg * PS;
@@ -162,7 +167,11 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN) / 4) conv3x3_wgrad_ker
                 const int coc = co < a.cout ? co : a.cout - 1;
                 const size_t rowo = ((size_t)b * a.cout + coc) * HW + (size_t)y * W + x0;   // wave-uniform
                 pdy[k] = a.dy[rowo + lane_c];
-                pg[k] = gate_act ? a.gate[rowo + lane_c] : 1.f;
+                if constexpr (!MASK) pg[k] = gate_act ? a.gate[rowo + lane_c] : 1.f;
+            }
+            if constexpr (MASK) {      // the wave's DR channels share one mask word per pixel (DR divides 32)
+                const int w = (co_base + wave * DR) >> 5;
+                pmask = a.gate_mask[((size_t)b * mask_nw + (w < mask_nw ? w : 0)) * HW + (size_t)y * W + x0 + lane_c];
             }
         };
         auto store_dy = [&](int buf) {      // mask + act' multiply happen here, after the MFMAs that hid the loads
@@ -171,7 +180,9 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN) / 4) conv3x3_wgrad_ker
 #pragma unroll
                 for (int k = 0; k < DR; ++k) {
                     const bool ok = co_base + wave * DR + k < a.cout && lane < ps;
-                    const float v = gate_act ? pdy[k] * scm_act_grad_from_out(pg[k], gate_act) : pdy[k];
+                    float v;
+                    if constexpr (MASK) v = pdy[k] * (((pmask >> ((wave * DR + k) & 31)) & 1u) ? 1.f : 0.01f);
+                    else v = gate_act ? pdy[k] * scm_act_grad_from_out(pg[k], gate_act) : pdy[k];
                     dyb[(wave * DR + k) * DPL + lane] = ok ? v : 0.f;
                 }
             }
@@ -560,12 +571,12 @@ extern "C" int scm_conv3x3_wgrad_workspace(int B, int H, int W, int cin, int cou
     return SCM_OK;
 }
 
-template <int WM, int WN, int NTW>
-static int launch_wgrad(const WgradKArgs& a, const WgradPlan& p, hipStream_t s) {
+template <int WM, int WN, int NTW, bool MASK>
+static int launch_wgrad_m(const WgradKArgs& a, const WgradPlan& p, hipStream_t s) {
     constexpr int MT = WM, NT = WN * NTW;
     const int PSP = a.PS + 4, XPL = (4 * PSP) | 1, DPL = (a.PS + 2) | 1;
     const size_t lds = ((size_t)NT * 32 * XPL + (size_t)2 * MT * 32 * DPL) * sizeof(float);
-    auto kern = conv3x3_wgrad_kernel<WM, WN, NTW>;
+    auto kern = conv3x3_wgrad_kernel<WM, WN, NTW, MASK>;
     static bool attr_set = false;
     if (!attr_set) {
         int rc = scm_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -578,6 +589,12 @@ static int launch_wgrad(const WgradKArgs& a, const WgradPlan& p, hipStream_t s) 
     hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, s, a);
     SCM_LAUNCH_CHECK("conv3x3_wgrad_kernel");
     return SCM_OK;
+}
+
+template <int WM, int WN, int NTW>
+static int launch_wgrad(const WgradKArgs& a, const WgradPlan& p, hipStream_t s) {
+    if (a.gate_mask != nullptr && a.gate_act == SCM_ACT_LRELU) return launch_wgrad_m<WM, WN, NTW, true>(a, p, s);
+    return launch_wgrad_m<WM, WN, NTW, false>(a, p, s);
 }
 
 static int wgrad_impl(const scm_conv3x3_wgrad_desc* d, int precision, void* stream) {
@@ -601,6 +618,7 @@ static int wgrad_impl(const scm_conv3x3_wgrad_desc* d, int precision, void* stre
     a.B = d->B; a.H = d->H; a.W = d->W; a.pad_mode = d->pad_mode;
     a.spi = p.spi; a.rows_per_split = p.rows_per_split; a.nseg = p.nseg; a.PS = p.PS;
     a.ci_groups = p.ci_groups;
+    a.gate_mask = d->gate_mask;
     hipStream_t s = (hipStream_t)stream;
     int rc;
     if (precision != SCM_PREC_F32 && d->cout > 64 && p.m16 == 0 && p.mt == 4) {

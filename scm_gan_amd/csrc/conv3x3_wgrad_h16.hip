@@ -104,6 +104,9 @@ __global__ void __launch_bounds__(256 * WN, 1) conv3x3_wgrad_h16_kernel(const Wg
     const float* dsrc[DT];
     const float* gsrc[DT];
     bool dvalid[DT];
+    int dbit[DT];
+    const bool use_mask = a.gate_mask != nullptr && gate_act == SCM_ACT_LRELU;
+    const int mask_nw = (a.cout + 31) >> 5;
 #pragma unroll
     for (int j = 0; j < DT; ++j) {
         const int co = co_base + (tid >> 3) + DSTEP * j;
@@ -111,6 +114,13 @@ __global__ void __launch_bounds__(256 * WN, 1) conv3x3_wgrad_h16_kernel(const Wg
         const size_t o = ((size_t)b * a.cout + (dvalid[j] ? co : 0)) * HW;
         dsrc[j] = a.dy + o;
         gsrc[j] = (gated ? a.gate : a.dy) + o;
+        // 1-bit gate: the mask words of this channel's 32-group travel through the same float
+        // registers (loads do not touch the bits) and are decoded when the row is staged
+        dbit[j] = co & 31;
+        if (use_mask) {
+            const int w = (dvalid[j] ? co : 0) >> 5;
+            gsrc[j] = reinterpret_cast<const float*>(a.gate_mask + ((size_t)b * mask_nw + w) * HW);
+        }
     }
     float csum[DT];
 #pragma unroll
@@ -201,7 +211,8 @@ __global__ void __launch_bounds__(256 * WN, 1) conv3x3_wgrad_h16_kernel(const Wg
                 for (int i = 0; i < 8; ++i) {
                     const int c = dc0 + i;
                     float t = pd[j][i];
-                    if (gated) t *= scm_act_grad_from_out(pgv[j][i], gate_act);
+                    if (use_mask) t *= ((__float_as_uint(pgv[j][i]) >> dbit[j]) & 1u) ? 1.f : 0.01f;
+                    else if (gated) t *= scm_act_grad_from_out(pgv[j][i], gate_act);
                     v[i] = (dvalid[j] && c < x0 + ps) ? t : 0.f;
                     s += v[i];
                 }

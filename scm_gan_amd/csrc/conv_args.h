@@ -14,6 +14,7 @@ struct ConvKArgs {
     int B; int H; int W;
     int pad_mode; int act;
     int tiles_per_img; int plane;
+    const unsigned* mask_in; unsigned* mask_out;   // 1-bit leaky-relu gate, words [B][ceil(C/32)][HW] (scm_hip.h)
 };
 
 

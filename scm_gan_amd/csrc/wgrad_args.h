@@ -10,6 +10,7 @@ struct WgradKArgs {
     int B; int H; int W; int pad_mode;
     int spi; int rows_per_split; int nseg; int PS;
     int ci_groups;
+    const unsigned* gate_mask;     // 1-bit leaky-relu gate, words [B][ceil(cout/32)][HW], or null
 };
 
 struct WgradPlan {

@@ -4,6 +4,7 @@ every FLOP and byte of these operators runs in libscmgan_hip.so.  There is no
 fallback: tensors must be fp32 CUDA tensors and the library must be built.
 """
 import ctypes
+import os
 
 import torch
 from torch.autograd import Function
@@ -121,14 +122,21 @@ def conv_kernel_name(cout, prec=0):
     return "conv3x3_mfma_kernel<%s>" % ("4,2|4,4" if cout > 64 else ("2,4" if cout > 32 else "1,8"))
 
 
-def _conv3x3_raw(x1, x2, gate1, gate2, gate_act, wpack, cout, scale, bias, sbias, co1, pad, act, prec=0):
+# The leaky-relu gate of the gradient kernels travels as a 1-bit mask written by the forward
+# epilogue (scm_conv3x3_desc.gate_mask_out): a gradient convolution then loads one word per pixel
+# and 32 channels instead of 32 floats.  Layers with cout <= 32 keep the float gate only.
+use_gate_mask = os.environ.get("SCM_NO_GATE_MASK", "0") in ("", "0")
+
+
+def _conv3x3_raw(x1, x2, gate1, gate2, gate_act, wpack, cout, scale, bias, sbias, co1, pad, act, prec=0,
+                 mask_out=None, mask_in=None):
     lib = L.lib()
     B, c1, H, W = x1.shape
     c2 = 0 if x2 is None else x2.shape[1]
     y1 = _new(x1, B, co1, H, W)
     y2 = _new(x1, B, cout - co1, H, W) if co1 < cout else None
     d = L.ConvDesc(_p(x1), _p(x2), c1, c2, _p(gate1), _p(gate2), gate_act, _p(wpack), cout, _p(scale), _p(bias),
-                   _p(sbias), _p(y1), _p(y2), co1, B, H, W, pad, act)
+                   _p(sbias), _p(y1), _p(y2), co1, B, H, W, pad, act, _p(mask_out), _p(mask_in))
     if kernel_timer is not None:
         ev = kernel_timer.bracket(conv_kernel_name(cout, prec), 2.0 * B * H * W * cout * (c1 + c2) * 9)
         ev[0].record()
@@ -228,10 +236,14 @@ class Conv3x3Fn(Function):
             sbias = _new(x1, B, cout)
             L.check(lib.scm_action_bias(_p(act_vec), _p(w), _p(inv_sigma), B, A, cout, cin_total, c1 + c2, _p(sbias),
                                         _stream()), "scm_action_bias")
+        mask = None
+        if use_gate_mask and cfg["act"] == ACT_LRELU and cout > 32:
+            mask = torch.empty((B, (cout + 31) // 32, H, W), device=x1.device, dtype=torch.int32)
         y, _ = _conv3x3_raw(x1, x2, None, None, 0, fpack, cout, inv_sigma, bias, sbias, cout, cfg["pad"], cfg["act"],
-                            fprec)
+                            fprec, mask_out=mask)
         ctx.cfg = cfg
         ctx.dprec = dprec
+        ctx.mask = mask
         ctx.shape = (B, c1, c2, H, W, cout, cin_total)
         ctx.has = (x2 is not None, act_vec is not None, bias is not None, inv_sigma is not None)
         ctx.params = (weight, bias)          # the Parameter objects: their .grad is looked up at backward time
@@ -250,7 +262,7 @@ class Conv3x3Fn(Function):
         dx1 = dx2 = d_act = dw = db = None
         if need_x1 or need_x2:
             dx1, dx2 = _conv3x3_raw(gy, None, y if act else None, None, act, dpack, c1 + c2, inv_sigma, None, None, c1,
-                                    cfg["pad"], ACT_NONE, ctx.dprec)
+                                    cfg["pad"], ACT_NONE, ctx.dprec, mask_in=ctx.mask)
         if need_w or need_b or need_a:
             pf, cf = ctypes.c_size_t(), ctypes.c_size_t()
             L.check(lib.scm_conv3x3_wgrad_workspace(B, H, W, c1 + c2, cout, ctypes.byref(pf), ctypes.byref(cf)),
@@ -272,7 +284,7 @@ class Conv3x3Fn(Function):
                 dot_part = _new(gy, (9 * cout * (c1 + c2) + 255) // 256)
             d = L.WgradDesc(_p(x1), _p(x2), c1, c2, _p(gy), _p(y) if act else None, act, cout, _p(dw_eff), _p(db),
                             _p(csum), _p(part), _p(cws), B, H, W, cfg["pad"], int(cfg["transposed"]), acc_flag,
-                            cin_total, 0, _p(w) if dot_part is not None else None, _p(dot_part))
+                            cin_total, 0, _p(w) if dot_part is not None else None, _p(dot_part), _p(ctx.mask))
             if ctx.dprec:
                 L.check(lib.scm_conv3x3_wgrad_h16(ctypes.byref(d), ctx.dprec, _stream()), "scm_conv3x3_wgrad_h16")
             else:

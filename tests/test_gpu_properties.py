@@ -165,3 +165,55 @@ def test_train_step_gradients_vs_oracle_on_odd_shapes(shape):
             g = ost[k].grad
             solid = g.abs() > 1e-6 if g is not None else torch.ones_like(ref, dtype=torch.bool)
             assert float(err[solid].max() if solid.any() else 0.0) < 2e-5, (name, k, float(err[solid].max()))
+
+
+@pytest.mark.parametrize("B,cin,cout,H,W,circ,prec", [
+    (2, 40, 128, 16, 16, 1, 0), (3, 16, 64, 20, 12, 0, 0), (64, 128, 128, 64, 64, 1, 0), (1, 48, 100, 84, 84, 0, 0),
+    (2, 40, 128, 16, 16, 1, 1), (8, 128, 128, 64, 64, 1, 1), (1, 48, 100, 33, 17, 0, 1)])
+def test_gate_mask_is_the_sign_of_y_and_gives_identical_gradients(B, cin, cout, H, W, circ, prec):
+    """The 1-bit leaky-relu gate written by the forward epilogue is exactly (y > 0), and the gradient
+    kernels produce BITWISE the same dx / dw / db from it as from the float gate (fp32 and 16-bit kernels)."""
+    import ctypes
+    from scm_gan_amd import _lib as L, ops
+    lib = L.lib()
+    P = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+    S = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    torch.manual_seed(5)
+    ops.set_compute_precision("fp16" if prec else "fp32")
+    try:
+        x = torch.randn(B, cin, H, W, device="cuda")
+        w = torch.randn(cout, cin, 3, 3, device="cuda") * 0.05
+        bias = torch.randn(cout, device="cuda") * 0.1
+        fp, dp, fprec, dprec = ops.pack_conv3x3(w, cin, cout)
+        nw = (cout + 31) // 32
+        mask = torch.zeros(B, nw, H, W, device="cuda", dtype=torch.int32)
+        y, _ = ops._conv3x3_raw(x, None, None, None, 0, fp, cout, None, bias, None, cout, circ, ops.ACT_LRELU, fprec,
+                                mask_out=mask)
+        bits = (y > 0).cpu().numpy()
+        m = mask.cpu().numpy().astype(np.uint32)
+        for c in range(cout):
+            got = (m[:, c // 32] >> np.uint32(c % 32)) & np.uint32(1)
+            assert np.array_equal(got.astype(bool), bits[:, c]), "channel %d" % c
+        gy = torch.randn(B, cout, H, W, device="cuda") * 1e-4
+        dx_f, _ = ops._conv3x3_raw(gy, None, y, None, ops.ACT_LRELU, dp, cin, None, None, None, cin, circ, ops.ACT_NONE, dprec)
+        dx_m, _ = ops._conv3x3_raw(gy, None, y, None, ops.ACT_LRELU, dp, cin, None, None, None, cin, circ, ops.ACT_NONE, dprec,
+                                   mask_in=mask)
+        assert torch.equal(dx_f, dx_m)
+        pf, cf = ctypes.c_size_t(), ctypes.c_size_t()
+        lib.scm_conv3x3_wgrad_workspace(B, H, W, cin, cout, ctypes.byref(pf), ctypes.byref(cf))
+        part = torch.empty(pf.value, device="cuda")
+        cws = torch.empty(cf.value, device="cuda")
+        outs = []
+        for mk in (None, mask):
+            dw = torch.empty_like(w)
+            db = torch.empty(cout, device="cuda")
+            d = L.WgradDesc(P(x), None, cin, 0, P(gy), P(y), ops.ACT_LRELU, cout, P(dw), P(db), None, P(part), P(cws), B, H, W,
+                            circ, 0, 0, 0, 0, None, None, P(mk))
+            if dprec:
+                L.check(lib.scm_conv3x3_wgrad_h16(ctypes.byref(d), dprec, S()), "wgrad_h16")
+            else:
+                L.check(lib.scm_conv3x3_wgrad(ctypes.byref(d), S()), "wgrad")
+            outs.append((dw, db))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    finally:
+        ops.set_compute_precision("fp32")
