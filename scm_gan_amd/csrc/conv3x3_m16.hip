@@ -20,7 +20,8 @@
 
 #define M16_PT 8     // 16-pixel tiles per wave
 
-template <int NJ, bool GATED>
+// GATED: 0 plain input, 1 input * act'(gate tensor), 2 input * leaky-relu slope from the 1-bit gate mask
+template <int NJ, int GATED>
 __global__ void __launch_bounds__(256, 2) conv3x3_m16_kernel(const ConvKArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int PLANE = NJ * 256 + 16;       // +16: the four ci groups of a wave land on different banks
@@ -91,7 +92,9 @@ __global__ void __launch_bounds__(256, 2) conv3x3_m16_kernel(const ConvKArgs a) 
     const float* wsrc = a.wpack;
     const int wmax = cin * 9 * 32 - 1;
 
-    float pw[WR], px[KC][NJ], pg[KC][NJ];
+    float pw[WR], px[KC][NJ], pg[GATED == 1 ? KC : 1][GATED == 1 ? NJ : 1];
+    unsigned pm[GATED == 2 ? NJ : 1];
+    const int mask_nw = (a.c1 + 31) >> 5;
     auto fetch = [&](int ci0) {
 #pragma unroll
         for (int k = 0; k < WR; ++k) {
@@ -110,11 +113,17 @@ __global__ void __launch_bounds__(256, 2) conv3x3_m16_kernel(const ConvKArgs a) 
             const float* src = (first ? a.x1 : a.x2) + o;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) px[c][j] = src[goff[j]];
-            if constexpr (GATED) {
+            if constexpr (GATED == 1) {
                 const float* gsrc = (first ? a.gate1 : a.gate2) + o;
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) pg[c][j] = gsrc[goff[j]];
             }
+        }
+        if constexpr (GATED == 2) {
+            const int w = (ci0 < cin ? ci0 : 0) >> 5;
+            const unsigned* mrow = a.mask_in + ((size_t)b * mask_nw + w) * HW;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) pm[j] = mrow[goff[j]];
         }
     };
     auto store = [&](int ci0) {
@@ -130,7 +139,8 @@ __global__ void __launch_bounds__(256, 2) conv3x3_m16_kernel(const ConvKArgs a) 
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 float v = px[c][j];
-                if constexpr (GATED) v *= scm_act_grad_from_out(pg[c][j], gate_act);
+                if constexpr (GATED == 1) v *= scm_act_grad_from_out(pg[c][j], gate_act);
+                if constexpr (GATED == 2) v *= ((pm[j] >> ((ci0 & 31) + c)) & 1u) ? 1.f : 0.01f;
                 xl[c * PLANE + tid + 256 * j] = (cvalid && (okmask & (1u << j))) ? v : 0.f;
             }
         }
@@ -185,7 +195,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_m16_kernel(const ConvKArgs a) 
     }
 }
 
-template <int NJ, bool GATED>
+template <int NJ, int GATED>
 static int launch_m16(const ConvKArgs& a, hipStream_t s) {
     constexpr int WR = (KC * 9 * 16 + 255) / 256;
     const size_t lds = ((size_t)WR * 256 + (size_t)KC * (NJ * 256 + 16)) * sizeof(float);
@@ -211,10 +221,12 @@ int scm_launch_conv3x3_m16(const ConvKArgs& k, hipStream_t s) {
     int rows = (NP % a.W == 0) ? NP / a.W : (NP + a.W - 2) / a.W + 1;
     if (rows > a.H) rows = a.H;
     a.plane = (rows + 2) * (a.W + 2);
-    const bool gated = a.gate_act != 0;
-    if (a.plane <= 3 * 256) return gated ? launch_m16<3, true>(a, s) : launch_m16<3, false>(a, s);
-    if (a.plane <= 5 * 256) return gated ? launch_m16<5, true>(a, s) : launch_m16<5, false>(a, s);
-    if (a.plane <= 8 * 256) return gated ? launch_m16<8, true>(a, s) : launch_m16<8, false>(a, s);
+    const int g = a.gate_act == 0 ? 0 : ((a.mask_in && a.gate_act == SCM_ACT_LRELU && a.c2 == 0) ? 2 : 1);
+#define SCM_M16_G(NJ_) (g == 2 ? launch_m16<NJ_, 2>(a, s) : (g == 1 ? launch_m16<NJ_, 1>(a, s) : launch_m16<NJ_, 0>(a, s)))
+    if (a.plane <= 3 * 256) return SCM_M16_G(3);
+    if (a.plane <= 5 * 256) return SCM_M16_G(5);
+    if (a.plane <= 8 * 256) return SCM_M16_G(8);
+#undef SCM_M16_G
     scm_set_error("scm_conv3x3: image width %d too large for the halo staging map", a.W);
     return SCM_EUNSUPPORTED;
 }

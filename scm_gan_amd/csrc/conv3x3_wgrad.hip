@@ -293,7 +293,7 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN) / 4) conv3x3_wgrad_ker
 // tile would be half (or 29/32) padding.  A = dyp[co (lane&15)][4 pixels (lane>>4)],
 // B = x[4 pixels][ci (lane&15)]; 8 waves (two per SIMD), wave w owns ci tile w of the
 // workgroup's 128 input channels and its 9 tap accumulators (36 registers).
-template <int NCO, int NCI>
+template <int NCO, int NCI, bool MASK>
 __global__ void __launch_bounds__(512, 2) conv3x3_wgrad_m16_kernel(const WgradKArgs a) {
     static_assert(NCO * NCI == 8, "8 waves");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -345,7 +345,10 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wgrad_m16_kernel(const WgradKA
     const float* hsrc = xbase(hc < NCIC ? hc : 0, hvalid);
     hvalid = hvalid && hc < NCIC;
 
-    float pdy[DR], pg[DR], px[XR], phalo = 0.f;
+    float pdy[DR], pg[MASK ? 1 : DR], px[XR], phalo = 0.f;
+    unsigned pmask = 0u;
+    static_assert(!MASK || 32 % DR == 0, "a wave's dy channels must not straddle mask words");
+    const int mask_nw = (a.cout + 31) >> 5;
 
     for (int seg = 0; seg < a.nseg; ++seg) {
         const int x0 = seg * PS;
@@ -402,7 +405,11 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wgrad_m16_kernel(const WgradKA
                 const int coc = co < a.cout ? co : a.cout - 1;
                 const size_t rowo = ((size_t)b * a.cout + coc) * HW + (size_t)y * W + x0;
                 pdy[k] = a.dy[rowo + lane_c];
-                pg[k] = gate_act ? a.gate[rowo + lane_c] : 1.f;
+                if constexpr (!MASK) pg[k] = gate_act ? a.gate[rowo + lane_c] : 1.f;
+            }
+            if constexpr (MASK) {
+                const int w = (co_base + wave * DR) >> 5;
+                pmask = a.gate_mask[((size_t)b * mask_nw + (w < mask_nw ? w : 0)) * HW + (size_t)y * W + x0 + lane_c];
             }
         };
         auto store_dy = [&]() {
@@ -410,7 +417,9 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wgrad_m16_kernel(const WgradKA
 #pragma unroll
                 for (int k = 0; k < DR; ++k) {
                     const bool ok = co_base + wave * DR + k < a.cout && lane < ps;
-                    const float v = gate_act ? pdy[k] * scm_act_grad_from_out(pg[k], gate_act) : pdy[k];
+                    float v;
+                    if constexpr (MASK) v = pdy[k] * (((pmask >> ((wave * DR + k) & 31)) & 1u) ? 1.f : 0.01f);
+                    else v = gate_act ? pdy[k] * scm_act_grad_from_out(pg[k], gate_act) : pdy[k];
                     dyl[(wave * DR + k) * DPL + lane] = ok ? v : 0.f;
                 }
             }
@@ -630,14 +639,18 @@ static int wgrad_impl(const scm_conv3x3_wgrad_desc* d, int precision, void* stre
         const int nci = p.m16 == 1 ? 128 : 16, nco = p.m16 == 1 ? 16 : 128;
         const int PSP = a.PS + 6, XPL = (3 * PSP) | 1, DPL = (a.PS + 4) | 1;
         const size_t lds = ((size_t)nci * XPL + (size_t)nco * DPL) * sizeof(float);
-        auto kern = p.m16 == 1 ? conv3x3_wgrad_m16_kernel<1, 8> : conv3x3_wgrad_m16_kernel<8, 1>;
-        static bool attr_set[2] = {false, false};
-        if (!attr_set[p.m16 - 1]) {
+        // the 1-bit gate serves the 128-co form (a wave's 16 channels sit in one mask word)
+        const bool mk = p.m16 == 2 && a.gate_mask != nullptr && a.gate_act == SCM_ACT_LRELU;
+        auto kern = p.m16 == 1 ? conv3x3_wgrad_m16_kernel<1, 8, false>
+                               : (mk ? conv3x3_wgrad_m16_kernel<8, 1, true> : conv3x3_wgrad_m16_kernel<8, 1, false>);
+        static bool attr_set[3] = {false, false, false};
+        const int ai = p.m16 == 1 ? 0 : (mk ? 2 : 1);
+        if (!attr_set[ai]) {
             rc = scm_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
                                "hipFuncSetAttribute");
             if (rc) return rc;
-            attr_set[p.m16 - 1] = true;
+            attr_set[ai] = true;
         }
         hipLaunchKernelGGL(kern, dim3(p.nsplit, p.co_groups * p.ci_groups), dim3(512), lds, s, a);
         SCM_LAUNCH_CHECK("conv3x3_wgrad_m16_kernel");

@@ -169,7 +169,8 @@ def test_train_step_gradients_vs_oracle_on_odd_shapes(shape):
 
 @pytest.mark.parametrize("B,cin,cout,H,W,circ,prec", [
     (2, 40, 128, 16, 16, 1, 0), (3, 16, 64, 20, 12, 0, 0), (64, 128, 128, 64, 64, 1, 0), (1, 48, 100, 84, 84, 0, 0),
-    (2, 40, 128, 16, 16, 1, 1), (8, 128, 128, 64, 64, 1, 1), (1, 48, 100, 33, 17, 0, 1)])
+    (2, 40, 128, 16, 16, 1, 1), (8, 128, 128, 64, 64, 1, 1), (1, 48, 100, 33, 17, 0, 1),
+    (2, 16, 128, 16, 16, 1, 0), (3, 9, 64, 20, 12, 0, 0), (16, 16, 128, 64, 64, 1, 1)])
 def test_gate_mask_is_the_sign_of_y_and_gives_identical_gradients(B, cin, cout, H, W, circ, prec):
     """The 1-bit leaky-relu gate written by the forward epilogue is exactly (y > 0), and the gradient
     kernels produce BITWISE the same dx / dw / db from it as from the float gate (fp32 and 16-bit kernels)."""
