@@ -273,7 +273,9 @@ __global__ void __launch_bounds__(256, 1) conv3x3_h16_kernel(const ConvKArgs a) 
     // LDS region instead and stores float4s: whole 512-byte row runs, a quarter of the instructions.
     constexpr int EP = NPW + 4;                     // floats per channel row (+16 B: rows on different banks)
     float* ep = reinterpret_cast<float*>(smem16) + wave * (32 * EP);
-    const bool vec = (HW & 3) == 0;
+    // 16-byte stores need 16-byte aligned rows: H*W % 4 == 0 and aligned base pointers (wave-uniform)
+    const bool vec = (HW & 3) == 0 && ((reinterpret_cast<size_t>(a.y1) | reinterpret_cast<size_t>(a.y2) |
+                                         reinterpret_cast<size_t>(a.mask_out)) & 15) == 0;
     __syncthreads();                                // every wave is done reading the stage buffers
 #pragma unroll
     for (int m = 0; m < CT; ++m) {

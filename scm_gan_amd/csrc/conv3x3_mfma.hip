@@ -276,7 +276,9 @@ __global__ void __launch_bounds__(256, WPS) conv3x3_mfma_kernel(const ConvKArgs 
         // register otherwise).
         constexpr int EP = NPW + 4;
         float* ep = smem + wave * (32 * EP);
-        const bool vec = (HW & 3) == 0;
+        // 16-byte stores need 16-byte aligned rows: H*W % 4 == 0 and aligned base pointers (wave-uniform)
+        const bool vec = (HW & 3) == 0 && ((reinterpret_cast<size_t>(a.y1) | reinterpret_cast<size_t>(a.y2) |
+                                             reinterpret_cast<size_t>(a.mask_out)) & 15) == 0;
         __syncthreads();                                // every wave is done reading the stage
 #pragma unroll
         for (int m = 0; m < CT; ++m) {

@@ -306,7 +306,7 @@ int scm_launch_wgrad_h16(const WgradKArgs& a, const WgradPlan& p, int precision,
     }
     const bool vec = (a.W % 4 == 0) && (a.PS % 8 == 0) &&
                      ((reinterpret_cast<size_t>(a.x1) | reinterpret_cast<size_t>(a.x2) | reinterpret_cast<size_t>(a.dy) |
-                       reinterpret_cast<size_t>(a.gate)) % 16 == 0);
+                       reinterpret_cast<size_t>(a.gate) | reinterpret_cast<size_t>(a.gate_mask)) % 16 == 0);
     const bool narrow = p.ci_groups == 1 && a.c1 + a.c2 <= 32;      // one ci tile: 4 waves
     if (precision == SCM_PREC_F16) {
         if (narrow) return vec ? launch_wgrad_h16<SCM_PREC_F16, true, 1>(a, p, s) : launch_wgrad_h16<SCM_PREC_F16, false, 1>(a, p, s);
