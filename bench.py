@@ -271,10 +271,11 @@ def main():
             dom = max(summ.items(), key=lambda kv: kv[1]["ms"])
             name, s = dom
             achieved = s["flops"] / (s["ms"] * 1e-3) / 1e12
-            traffic = None       # HBM bytes per launch from the committed PMC passes (profiles/round1_pmc.json)
+            traffic = None       # HBM bytes per launch from the committed PMC passes (profiles/round1_pmc2.json)
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc.json")))["kernels"]
-                key = [k for k in pmc if name.split("<")[0] in k and "false" in k]
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc2.json")))["kernels"]
+                want = "conv3x3_h16_kernel<1," if "h16" in name else "conv3x3_mfma_kernel<4, 2, 2, 0,"
+                key = [k for k in pmc if want in k]
                 traffic = pmc[key[0]]["hbm_traffic_bytes"] if key else None
             except Exception:
                 pass
