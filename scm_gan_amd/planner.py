@@ -12,6 +12,7 @@ power iterations included) is replayed exactly as in eager mode.
 import numpy as np
 import torch
 
+from . import ops
 from .main import onehot
 
 
@@ -27,6 +28,12 @@ class GraphedRollout(object):
         self._graph = None
         self._z_in = None
         self._out = None
+        self._stamp = None
+
+    def _weights_stamp(self):
+        """The graph holds the weight packs that were current at capture: recapture after any update."""
+        ps = list(self.transition.parameters()) + list(self.reward_predictor.parameters())
+        return (ops.weights_epoch(), ops.compute_precision(), tuple(p._version for p in ps), tuple(p.data_ptr() for p in ps))
 
     def _rollout(self, z):
         z = z.repeat(self.width, 1, 1, 1)
@@ -43,7 +50,9 @@ class GraphedRollout(object):
         """z: (1, latent, H, W) start latent. Returns the best cumulative reward (0-dim tensor)."""
         if self.transition.training or self.reward_predictor.training:
             raise RuntimeError("GraphedRollout is the eval-mode planner path: call test_mode() first")
-        if self._graph is None or self._z_in.shape != z.shape:
+        stamp = self._weights_stamp()
+        if self._graph is None or self._z_in.shape != z.shape or stamp != self._stamp:
+            self._stamp = stamp
             self._z_in = z.clone()
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())

@@ -252,3 +252,23 @@ def test_graphed_planner_matches_eager_and_is_faster():
         t_eager = (time.perf_counter() - t0) / 5
     print("planner: graph %.2f ms  eager %.2f ms" % (t_graph * 1e3, t_eager * 1e3))
     assert t_graph < t_eager
+
+
+def test_graphed_planner_recaptures_after_a_weight_update():
+    import copy
+    from scm_gan_amd import main as T
+    from scm_gan_amd.planner import GraphedRollout
+    enc, dec, rp, disc, tr = build(111)
+    T.test_mode([tr, rp])
+    z = dev((np.random.default_rng(6).random((1, 16, 32, 32)) < 0.5).astype(np.float32))
+    planner = GraphedRollout(tr, rp, 5)
+    with torch.no_grad():
+        r0 = float(planner(z))
+        rp.conv2.bias.add_(0.25)                       # an in-place update bumps the parameter version
+        tr2, rp2 = copy.deepcopy(tr), copy.deepcopy(rp)
+        got = float(planner(z))                        # recapture: 2 warm-up rollouts + capture + replay = 4 rollouts
+        for _ in range(3):
+            T.compute_rollout_reward(z, tr2, rp2, 5, selected_action=0)
+        want = float(T.compute_rollout_reward(z, tr2, rp2, 5, selected_action=0))
+    assert abs(got - want) < 2e-3 * max(1.0, abs(want)), (got, want, r0)
+    assert abs(got - r0) > 1e-3
