@@ -274,6 +274,10 @@ int scm_step_loss(const float* rhat, const float* r, long r_stride, const float*
 int scm_step_loss_bwd(const float* rhat, const float* r, long r_stride, const float* mask, const float* g, int B,
                       int R, float coef, float* d_rhat, float* d_bce, void* stream);
 
+/* onehot(a_idx, num_actions) (main.py:447-452) on the device: out[n][num_actions], out[i][a] = (idx[i] == a);
+ * idx are int64 action indices already resident on the device (device batch interface). */
+int scm_onehot(const long long* idx, long n, int num_actions, float* out, void* stream);
+
 /* CoordConv2d input: out[B][C+2][H][W] = cat(x, coord_x, coord_y) (coordconv.py:12-14). */
 int scm_coord_cat(const float* x, float* out, int B, int C, int H, int W, void* stream);
 

@@ -118,6 +118,7 @@ def lib():
             "scm_coord_cat": [vp, vp, ci, ci, ci, ci, vp],
             "scm_step_loss": [vp, vp, ctypes.c_long, vp, ctypes.c_long, vp, vp, vp, ci, ci, cf, vp, vp, vp, vp],
             "scm_step_loss_bwd": [vp, vp, ctypes.c_long, vp, vp, ci, ci, cf, vp, vp, vp],
+            "scm_onehot": [vp, ctypes.c_long, ci, vp, vp],
             "scm_csrn_sweep_fwd": [vp, vp],
             "scm_csrn_sweep_bwd": [vp, vp, vp, vp, vp, vp],
             "scm_adam_clip_multi": [ci, vp, vp, vp, vp, vp, cf, cf, cf, cf, ci, cf, cf, vp],

@@ -462,3 +462,23 @@ extern "C" int scm_step_loss_bwd(const float* rhat, const float* r, long r_strid
     SCM_LAUNCH_CHECK("step_loss_bwd_kernel");
     return SCM_OK;
 }
+
+// ------------------------------------------------------------------ one-hot
+// onehot(a_idx, num_actions) of main.py:447-452 on the device: out[i][a] = (idx[i] == a).
+__global__ void onehot_kernel(const long long* __restrict__ idx, long n, int A, float* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n * A) {
+        const long row = i / A;
+        const int a = (int)(i - row * A);
+        out[i] = idx[row] == a ? 1.f : 0.f;
+    }
+}
+
+extern "C" int scm_onehot(const long long* idx, long n, int num_actions, float* out, void* stream) {
+    SCM_REQUIRE(idx && out && n > 0 && num_actions > 0, "scm_onehot: bad arguments");
+    const long total = n * num_actions;
+    hipLaunchKernelGGL(onehot_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, idx, n,
+                       num_actions, out);
+    SCM_LAUNCH_CHECK("onehot_kernel");
+    return SCM_OK;
+}

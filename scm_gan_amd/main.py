@@ -56,6 +56,9 @@ parser.add_argument('--seed', type=int, default=0, help='Seed of weights, data a
 parser.add_argument('--precision', choices=('fp32', 'fp16'), default='fp32',
                     help="MFMA operand precision of the 3x3 convs: fp32 = the reference's arithmetic; fp16 = fp16 forward / "
                          "bf16 gradient operands with fp32 accumulation (not in the reference)")
+parser.add_argument('--prefetch', type=int, default=0,
+                    help='Depth of the device-side batch queue (datasource.DeviceBatchQueue: worker thread, pinned '
+                         'double-buffered uploads, on-device one-hot); 0 = the reference\'s serial loop')
 parser.add_argument('--eval-every', type=int, default=2000, help='Evaluate + checkpoint cadence (ITERS_PER_VIDEO)')
 parser.add_argument('--log-every', type=int, default=10)
 
@@ -304,6 +307,14 @@ def train(latent_dim, datasource, num_actions, num_rewards,
                       transition)
     rank = trainer.rank
     ts = trainer.ts
+
+    def horizon_of(it):                                                        # main.py:143-145
+        return args.horizon_min + int((args.horizon_max - args.horizon_min) * (it / train_iters))
+    queue = None
+    if getattr(args, 'prefetch', 0) > 0:
+        from .datasource import DeviceBatchQueue
+        queue = DeviceBatchQueue(datasource, batch_size, [horizon_of(i) for i in range(args.start_iter, train_iters + 1)],
+                                 num_actions, depth=args.prefetch)
     for train_iter in range(args.start_iter, train_iters + 1):
         if train_iter % args.eval_every == 0:
             if rank == 0:
@@ -321,9 +332,13 @@ def train(latent_dim, datasource, num_actions, num_rewards,
         pred_delta = args.horizon_max - args.horizon_min
         prediction_horizon = args.horizon_min + int(pred_delta * theta)
 
-        states, rewards, dones, actions = datasource.get_trajectories(batch_size, prediction_horizon)
-        trainer.step(_upload(states), _upload(rewards), _upload(np.asarray(dones).astype(int)),
-                     onehot(actions, num_actions), theta, train_iter, actions)
+        if queue is not None:
+            d_states, d_rewards, d_dones, d_onehot, actions = queue.get()
+            trainer.step(d_states, d_rewards, d_dones, d_onehot, theta, train_iter, actions)
+        else:
+            states, rewards, dones, actions = datasource.get_trajectories(batch_size, prediction_horizon)
+            trainer.step(_upload(states), _upload(rewards), _upload(np.asarray(dones).astype(int)),
+                         onehot(actions, num_actions), theta, train_iter, actions)
         if rank == 0:
             ts.print_every(args.log_every)
     if rank == 0:

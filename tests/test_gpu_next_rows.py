@@ -272,3 +272,33 @@ def test_graphed_planner_recaptures_after_a_weight_update():
         want = float(T.compute_rollout_reward(z, tr2, rp2, 5, selected_action=0))
     assert abs(got - want) < 2e-3 * max(1.0, abs(want)), (got, want, r0)
     assert abs(got - r0) > 1e-3
+
+
+def test_device_batch_queue_matches_the_serial_loop(tmp_path, monkeypatch):
+    """train() fed by datasource.DeviceBatchQueue (worker thread, pinned double-buffered uploads, on-device
+    one-hot; --prefetch 2) ends with BITWISE the weights of the serial loop, growing horizon included."""
+    from scm_gan_amd import main as T, models as M, _lib as L
+    from scm_gan_amd.datasource import SyntheticDatasource
+    import ctypes
+    monkeypatch.chdir(tmp_path)
+    # the one-hot kernel against the reference formulation (eye[idx])
+    idx = torch.randint(0, 5, (7, 11), device="cuda")
+    oh = torch.empty(7, 11, 5, device="cuda")
+    L.check(L.lib().scm_onehot(ctypes.c_void_p(idx.data_ptr()), idx.numel(), 5, ctypes.c_void_p(oh.data_ptr()),
+                               ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "scm_onehot")
+    assert torch.equal(oh, torch.eye(5, device="cuda")[idx])
+
+    def run(prefetch):
+        torch.manual_seed(21)
+        enc, dec, rp, disc, tr = M.Encoder(16, 3), M.Decoder(16, 3), M.RewardPredictor(16, 2), M.Discriminator(), \
+            M.Transition(16, 5)
+        tr.seed_noise(9)
+        ds = SyntheticDatasource(seed=4, height=32, width=32, channels=3, num_actions=5, num_rewards=2, done_every=3)
+        T.args = T.parser.parse_args(["--batch-size", "6", "--train-iters", "7", "--horizon-min", "3", "--horizon-max", "8",
+                                      "--eval-every", "1000000", "--prefetch", str(prefetch)])
+        T.train(16, ds, 5, 2, enc, dec, rp, disc, tr)
+        return torch.cat([p.detach().flatten() for m in (enc, tr, dec, rp) for p in m.parameters()])
+
+    w_serial = run(0)
+    w_queue = run(2)
+    assert torch.equal(w_serial, w_queue)
