@@ -47,6 +47,7 @@ __global__ void __launch_bounds__(256, WPS) conv3x3_mfma_kernel(const ConvKArgs 
     constexpr int WLDS = WR * 256 * 4;             // weight region padded to whole thread passes
     constexpr int BUF = WLDS + KC * PLANE;         // floats per LDS stage
     constexpr bool DB = (NJ == 4) && WPS == 1;     // two LDS stages when they fit in 160 KB (one WG per CU)
+    constexpr int BIAS_F = (DB ? 2 : 1) * BUF;     // bias table (CW floats) behind the stage buffers
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -64,6 +65,15 @@ __global__ void __launch_bounds__(256, WPS) conv3x3_mfma_kernel(const ConvKArgs 
     if (plast > HW) plast = HW;
     const int nrows = (plast - 1) / W - r0 + 3;
     const int nelem = nrows * ROWPL;
+
+    if (tid < CW) {      // bias table for the epilogue (visible after the main loop's barriers)
+        const int co = blockIdx.y * CW + tid;
+        const int coc = co < a.cout ? co : a.cout - 1;
+        float v = 0.f;
+        if (a.bias) v += a.bias[coc];
+        if (a.sbias) v += a.sbias[(size_t)b * a.cout + coc];
+        smem[BIAS_F + tid] = v;
+    }
 
     // staging map: LDS element e = tid + 256*j  <-  plane offset goff[j] (clamped);
     // bit j of okmask: a real (or wrapped) pixel; other elements are written as 0
@@ -246,28 +256,15 @@ __global__ void __launch_bounds__(256, WPS) conv3x3_mfma_kernel(const ConvKArgs 
     // loop cost one serialized L2 round trip per accumulator register (45 us / WG).
     const float sc = a.scale ? *a.scale : 1.f;
     const int co2n = a.cout - a.co1;
+    // bias + per-sample bias come from the LDS table the prologue filled: 16*CT broadcast LDS
+    // reads instead of up to 32*CT global loads per thread
     float badd[CT][16];
-#pragma unroll
-    for (int m = 0; m < CT; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) badd[m][r] = 0.f;
-    if (a.bias) {
+    {
+        const float* bl = smem + BIAS_F;
 #pragma unroll
         for (int m = 0; m < CT; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = cg * CW + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                badd[m][r] += a.bias[co < a.cout ? co : a.cout - 1];
-            }
-    }
-    if (a.sbias) {
-#pragma unroll
-        for (int m = 0; m < CT; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = cg * CW + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                badd[m][r] += a.sbias[(size_t)b * a.cout + (co < a.cout ? co : a.cout - 1)];
-            }
+            for (int r = 0; r < 16; ++r) badd[m][r] = bl[m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
     }
     if constexpr (PT <= 4 && CT >= 2) {
         // cout > 32 variants (their LDS stage is larger than the four slabs): transpose each wave's 32-channel x NPW-pixel slab through its own
@@ -436,7 +433,8 @@ extern "C" int scm_pack_conv3x3_weights(const float* w, int cin, int cout, int t
 template <int CT, int PT, int NJ, int GATED, int WPS = 1>
 static int launch_conv_nj(const ConvKArgs& a, int groups, hipStream_t s) {
     constexpr int W4 = KC * 9 * CT * 32 / 4, WR = (W4 + 255) / 256;
-    const size_t lds = ((size_t)WR * 256 * 4 + (size_t)KC * NJ * 256) * sizeof(float) * ((NJ == 4 && WPS == 1) ? 2 : 1);
+    const size_t lds = ((size_t)WR * 256 * 4 + (size_t)KC * NJ * 256) * sizeof(float) * ((NJ == 4 && WPS == 1) ? 2 : 1) +
+                       CT * 32 * sizeof(float);       // + bias table
     auto kern = conv3x3_mfma_kernel<CT, PT, NJ, GATED, WPS>;
     static bool attr_set = false;
     if (!attr_set) {
