@@ -11,9 +11,10 @@ Mirrors /root/reference/datasource.py:8-120: a datasource exposes
            actions (B, T)          int
 
 as host numpy arrays (reference envs/minipacman.py:122-164).  The reference's
-simulators (gym, gym_minipacman, StarCraft II, ALE) are out of scope and not
+simulators that need gym_minipacman, StarCraft II or ALE are out of scope and not
 available offline; SyntheticDatasource produces batches of the same shapes and
-dtypes from a seeded numpy stream.
+dtypes from a seeded numpy stream.  Its three pure-numpy
+games ('pong', 'gridworld', 'gameoflife') are restated in simulators.py.
 """
 import numpy as np
 
@@ -74,6 +75,11 @@ def allocate_datasource(datasource_name, seed=0):
     if datasource_name in _SYNTHETIC:
         h, w, c, a, r = _SYNTHETIC[datasource_name]
         return SyntheticDatasource(seed=seed, height=h, width=w, channels=c, num_actions=a, num_rewards=r)
+    if datasource_name in ("pong", "gridworld", "gameoflife"):
+        # the reference's pure-numpy simulators, restated as batch datasources (simulators.py)
+        from . import simulators
+        return {"pong": simulators.Pong, "gridworld": simulators.GridWorld,
+                "gameoflife": simulators.GameOfLife}[datasource_name](seed=seed)
     if datasource_name in _REFERENCE_ENVS:
         raise ValueError(
             "datasource '%s' needs the reference's simulator stack (gym / gym_minipacman / sc2env), which is out "

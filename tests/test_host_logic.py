@@ -98,3 +98,82 @@ def test_timeseries_standin():
         ts.print_every(10)
     assert ts.values("a") == [0.0, 1.0, 2.0] and "a=2.0000" in str(ts)
     assert len(sparkline([1, 2, 3])) == 3
+
+
+# ---- the three numpy simulators restated in scm_gan_amd/simulators.py (parity unpinned: rule checks)
+def test_gameoflife_step_is_conways_rule_on_a_torus():
+    from scipy.signal import convolve2d
+    from scm_gan_amd.simulators import GameOfLife
+    g = GameOfLife(seed=3)
+    st = g.reset(5)
+    before = st["cells"].copy()
+    r = g.step(st, np.zeros(5, dtype=int))
+    kernel = np.ones((3, 3)); kernel[1, 1] = 0
+    for b in range(5):
+        n = convolve2d(before[b].astype(int), kernel, mode="same", boundary="wrap")      # envs/gameoflife.py:35-36
+        assert np.array_equal(st["cells"][b], (n == 3) | (before[b] & (n == 2)))
+    assert not r.any()
+    s, rw, d, a = g.get_trajectories(3, 6)
+    assert s.shape == (3, 6, 1, 64, 64) and rw.shape == (3, 6, 1) and d.shape == (3, 6) and a.shape == (3, 6)
+    assert set(np.unique(s)) <= {0.0, 1.0} and not a.any() and not d.any()
+
+
+def test_gridworld_moves_clamps_and_rewards():
+    from scm_gan_amd.simulators import GridWorld
+    g = GridWorld(seed=0)
+    st = {"x": np.array([8, 14, 2, 8, 8]), "y": np.array([8, 8, 8, 3, 13])}
+    r = g.step(st, np.array([0, 3, 2, 0, 1]))      # up, right, left, up, down
+    assert st["y"].tolist() == [5, 8, 8, 2, 14]      # y clamps to [2, 14]
+    assert st["x"].tolist() == [8, 16, 0, 8, 8]      # x clamps to [0, 16]
+    assert r.tolist() == [0, 1, -1, 0, 0]            # right wall +1, left wall -1
+    f = g.render({"x": np.array([8, 0, 16]), "y": np.array([8, 8, 8])})
+    assert f.shape == (3, 3, 16, 16) and f[:, 0].sum() == 0 and f[:, 2].sum() == 0
+    assert f[0, 1, 6:10, 6:10].all() and f[0, 1].sum() == 16          # rows/cols [c-2, c+2)
+    assert f[1, 1, 6:10, 0:2].all() and f[1, 1].sum() == 8            # clipped at the left edge
+    assert f[2, 1, 6:10, 14:15].all() and f[2, 1].sum() == 4          # right edge: [14, min(18, 15))
+    # the action stored at t is the one applied at t+1
+    g2 = GridWorld(seed=5)
+    s, rw, d, a = g2.get_trajectories(16, 8)
+    cy = np.array([[np.argwhere(s[b, t, 1].any(1)).mean() for t in range(8)] for b in range(16)])
+    up, down = (a[:, :-1] == 0), (a[:, :-1] == 1)
+    dy = cy[:, 1:] - cy[:, :-1]
+    assert (dy[up] <= 0).all() and (dy[down] >= 0).all() and (dy[~(up | down)] == 0).all()
+
+
+def test_pong_bounces_and_scores():
+    from scm_gan_amd.simulators import Pong
+    g = Pong(seed=0)
+    z = lambda *v: np.array(v)
+    # ball reaches the right paddle's column in front of the paddle: vx flips; same column away from it: goes on
+    st = {"left_y": z(32, 32), "right_y": z(32, 5), "bx": z(54, 54), "by": z(30, 30), "vx": z(2, 2), "vy": z(2, 2)}
+    r = g.step(st, z(2, 2))
+    assert st["bx"].tolist() == [56, 56] and st["vx"].tolist() == [-2, 2] and not r.any()
+    # top / bottom walls
+    st = {"left_y": z(32, 32), "right_y": z(32, 32), "bx": z(30, 30), "by": z(61, 4), "vx": z(2, 2), "vy": z(2, -3)}
+    g.step(st, z(0, 0))
+    assert st["vy"].tolist() == [-2, 3]
+    # leaving the court: +1 on the right, -1 on the left, and the ball is sent back
+    st = {"left_y": z(5, 5), "right_y": z(5, 5), "bx": z(62, 2), "by": z(40, 40), "vx": z(3, -3), "vy": z(2, 2)}
+    r = g.step(st, z(0, 0))
+    assert r.tolist() == [1, -1] and st["vx"].tolist() == [-3, 3]
+    # buttons: 0/1 red (right) paddle, 2/3 blue (left) paddle, clamped to the court
+    st = {"left_y": z(32, 32, 1, 32), "right_y": z(32, 63, 32, 32), "bx": z(30, 30, 30, 30), "by": z(30, 30, 30, 30),
+          "vx": z(2, 2, 2, 2), "vy": z(2, 2, 2, 2)}
+    g.step(st, z(0, 1, 2, 3))
+    assert st["right_y"].tolist() == [29, 64, 32, 32] and st["left_y"].tolist() == [32, 32, 0, 35]
+    f = g.render({"left_y": z(32), "right_y": z(20), "bx": z(40), "by": z(10), "vx": z(2), "vy": z(2)})
+    assert f[0, 2, 24:40, 4:6].all() and f[0, 2].sum() == 32          # blue paddle, left
+    assert f[0, 0, 12:28, 58:60].all() and f[0, 0].sum() == 32        # red paddle, right
+    assert f[0, 1, 8:12, 38:42].all() and f[0, 1].sum() == 16         # green ball
+    s, rw, d, a = g.get_trajectories(4, 5)
+    assert s.shape == (4, 5, 3, 64, 64) and rw.shape == (4, 5, 1) and a.max() <= 3
+
+
+def test_allocate_datasource_numpy_games():
+    from scm_gan_amd.datasource import allocate_datasource
+    for name, (c, size, acts) in {"pong": (3, 64, 4), "gridworld": (3, 16, 4), "gameoflife": (1, 64, 1)}.items():
+        ds = allocate_datasource(name, seed=2)
+        assert (ds.conv_input_channels, ds.height, ds.binary_input_channels, ds.scalar_output_channels) == (c, size, acts, 1)
+        a1 = allocate_datasource(name, seed=2).get_trajectories(2, 3)
+        a2 = ds.get_trajectories(2, 3)
+        assert all(np.array_equal(x, y) for x, y in zip(a1, a2))          # seeded: reproducible
