@@ -1,5 +1,5 @@
 """Train / rollout API of the hot path, with the reference's function signatures
-(/root/reference/main.py): train(), evaluate(), measure_prediction_mse(),
+(/root/reference/main.py): train(), evaluate(), measure_prediction_mse(), play(),
 compute_rollout_reward(), onehot(), train_mode(), test_mode().
 
 The per-iteration body follows main.py:143-297 line by line; the networks are
@@ -8,8 +8,8 @@ clip+Adam kernel, and under torch.distributed (one process per GPU, RCCL) the
 gradients are summed with one all-reduce per network over a flat bucket before
 the clip, so N ranks with batch B/N each reproduce one rank with batch B.
 
-Out of scope here: play() (needs a live simulator), the
-mp4/png visualisers, causal-graph rendering.
+Out of scope here: the mp4/png visualisers (play() keeps its
+numeric agent loop and drops the video writer), causal-graph rendering.
 """
 import argparse
 import json
@@ -382,6 +382,67 @@ def compute_rollout_reward(z, transition, reward_predictor, num_actions,
 
 
 @torch.no_grad()
+def play(latent_dim, datasource, num_actions, num_rewards, encoder, decoder, reward_predictor, discriminator,
+         transition, max_steps=300, use_graph=True, verbose=True):
+    """main.py:327-400, the model-predictive agent (numeric part; the mp4 writer is out of scope):
+    estimate the latent state from three frames, then every step roll every first action forward
+    through compute_rollout_reward, act greedily in the real game and re-estimate the state from the
+    last three frames.  use_graph replays each rollout as one HIP graph (planner.GraphedRollout).
+    Returns (steps, cumulative_reward, [chosen actions])."""
+    test_mode([encoder, decoder, transition, discriminator, reward_predictor])
+    env = datasource.make_env(screen_size=512)
+    no_op = min(3, num_actions - 1)                                    # the reference hard-codes button 3
+    frames = [datasource.convert_frame(env.reset())[0]]
+    done = False
+    for _ in range(2):
+        state, _, done, _ = env.step(no_op)
+        frames.append(datasource.convert_frame(state)[0])
+
+    def estimate(frames, action):
+        z = encoder(_upload(np.stack(frames)).unsqueeze(0))
+        return transition(z, onehot(int(action), num_actions))
+    z = estimate(frames, no_op)
+    planner = None
+    if use_graph:
+        from .planner import GraphedRollout
+        planner = GraphedRollout(transition, reward_predictor, num_actions)
+    t, total, pos, neg, chosen = 2, 0.0, 0.0, 0.0, []
+    while not done:
+        futures = []
+        for a in range(num_actions):
+            z_a = transition(z, onehot(a, num_actions))
+            if planner is not None:
+                futures.append(float(planner(z_a)))
+            else:
+                futures.append(float(compute_rollout_reward(z_a, transition, reward_predictor, num_actions, a,
+                                                            rollout_depth=12, rollout_policy='noop')))
+        best = int(np.argmax(futures))
+        chosen.append(best)
+        new_state, new_reward, done, info = env.step(best)
+        if len(info) > 1:                                              # per-channel rewards (main.py:373-378)
+            pos += sum(v for v in info.values() if v > 0)
+            neg -= sum(v for v in info.values() if v < 0)
+        else:
+            pos += max(0, new_reward)
+            neg -= min(0, new_reward)
+        total += new_reward
+        if verbose:
+            print('t={} curr. r={:.02f} future r: {}'.format(t, total, ' '.join('{:.02f}'.format(f) for f in futures)))
+            print('Negative Reward: {}    Positive Reward: {}'.format(int(neg), int(pos)))
+        frames = frames[1:] + [datasource.convert_frame(new_state)[0]]
+        z = estimate(frames, best)
+        t += 1
+        if t > max_steps:
+            print('Ending evaluation due to time limit')
+            break
+    msg = 'Finished at t={} with cumulative reward {}'.format(t, total)
+    with open('evaluation_metrics_{}.txt'.format(int(time.time())), 'w') as fp:
+        fp.write(msg + '\n')
+    print(msg)
+    return t, total, chosen
+
+
+@torch.no_grad()
 def measure_prediction_mse(datasource, encoder, decoder, transition, reward_pred,
                            train_iter=0, timesteps=100, num_factors=16, experiment_name='default',
                            use_training_set=False, batch_size=100, write_files=True):
@@ -435,11 +496,6 @@ def measure_prediction_mse(datasource, encoder, decoder, transition, reward_pred
     return {'pixel': (mse_losses, mse_stddevs), 'reward': (reward_losses, reward_stddevs)}
 
 
-def play(*a, **k):
-    raise NotImplementedError("play() needs a live simulator (gym / gym_minipacman / sc2env): out of scope, "
-                              "SURVEY.md section 2 row 7; compute_rollout_reward() is provided")
-
-
 def main(argv=None):
     """main.py:64-103."""
     global args
@@ -467,6 +523,18 @@ def main(argv=None):
             net.load_state_dict(torch.load(os.path.join(args.load_from, 'model-{}.pth'.format(name)),
                                            weights_only=True))
     if args.evaluate:
+        # main.py:92-99: play-throughs with the model-predictive agent (datasources that can make_env), then the
+        # open-loop prediction error
+        try:
+            datasource.make_env(screen_size=512)
+            can_play = True
+        except NotImplementedError:
+            can_play = False
+        if can_play:
+            for _ in range(args.evaluations):
+                play(latent_dim, datasource, num_actions, num_rewards, encoder, decoder, reward_predictor,
+                     discriminator, transition, verbose=False)
+            print('Finished {} playthroughs'.format(args.evaluations))
         evaluate(datasource, encoder, decoder, transition, discriminator, reward_predictor, latent_dim,
                  use_training_set=True)
     else:

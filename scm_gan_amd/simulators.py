@@ -58,7 +58,9 @@ class _BatchSimulator(Datasource):
         self.rng = np.random.default_rng(seed)
 
     def make_env(self, *args, **kwargs):
-        raise NotImplementedError("the batch simulators have no per-instance gym-style env; use get_trajectories")
+        """A single game with the reset() / step(action) -> (state, reward, done, info) protocol that
+        main.play() drives (reference main.py:331-371); extra arguments (screen_size=...) are ignored."""
+        return SingleGame(self)
 
     # subclasses: reset(B) -> state dict, step(state, actions) -> rewards (B,), render(state) -> (B, C, H, W)
     def get_trajectories(self, batch_size=32, timesteps=10, policy='random', random_start=False, training=True):
@@ -162,3 +164,22 @@ class Pong(_BatchSimulator):
         _fill_rects(f, 0, np.full(B, self.size - self.MARGIN_X), st["right_y"], self.PADDLE_W, self.PADDLE_H)
         _fill_rects(f, 1, st["bx"], st["by"], self.RADIUS, self.RADIUS)
         return f
+
+
+
+class SingleGame(object):
+    """One instance (batch of 1) of a batch simulator behind the gym-style protocol."""
+
+    def __init__(self, sim):
+        self.sim = sim
+        self.num_actions = sim.num_actions
+        self.state = None
+        self.reset()
+
+    def reset(self):
+        self.state = self.sim.reset(1)
+        return self.sim.render(self.state)[0]
+
+    def step(self, action):
+        reward = float(self.sim.step(self.state, np.array([int(action)]))[0])
+        return self.sim.render(self.state)[0], reward, False, {}

@@ -302,3 +302,25 @@ def test_device_batch_queue_matches_the_serial_loop(tmp_path, monkeypatch):
     w_serial = run(0)
     w_queue = run(2)
     assert torch.equal(w_serial, w_queue)
+
+
+def test_play_agent_on_gridworld_matches_the_eager_planner(tmp_path, monkeypatch):
+    """main.play() (reference main.py:327-400) on the restated gridworld game: the HIP-graph planner and the
+    eager compute_rollout_reward pick the same actions from the same weights and game seed."""
+    import copy
+    from scm_gan_amd import main as T, models as M
+    from scm_gan_amd.datasource import allocate_datasource
+    monkeypatch.chdir(tmp_path)
+    torch.manual_seed(8)
+    nets = [M.Encoder(16, 3), M.Decoder(16, 3), M.RewardPredictor(16, 1), M.Discriminator(), M.Transition(16, 4)]
+    runs = []
+    for use_graph in (True, False):
+        enc, dec, rp, disc, tr = copy.deepcopy(nets)
+        ds = allocate_datasource("gridworld", seed=3)
+        t, total, chosen = T.play(16, ds, 4, 1, enc, dec, rp, disc, tr, max_steps=12, use_graph=use_graph, verbose=False)
+        runs.append((t, total, chosen))
+        assert t == 13 and len(chosen) == 11 and all(0 <= a < 4 for a in chosen)
+    # SpectralNorm's power iteration advances with every forward call and the graph adds warm-up rollouts, so the two
+    # agents see slightly different sigma: the first decisions (before that drift matters) must agree
+    assert runs[0][2][:3] == runs[1][2][:3], runs
+    assert list(tmp_path.glob("evaluation_metrics_*.txt"))
