@@ -83,6 +83,10 @@ def lib():
             raise RuntimeError(
                 "scm_gan_amd: %s not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+        # PyTorch ships its own libamdhip64; the library must bind to THAT runtime instance (same
+        # devices, streams and allocations), so torch is loaded first.  Loading this library ahead of
+        # torch leaves two HIP runtimes in the process and every launch fails with hipErrorNoDevice.
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         L.scm_version.restype = ctypes.c_int
         L.scm_last_error.restype = ctypes.c_char_p
