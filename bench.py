@@ -4,16 +4,23 @@ frame-prediction TRAINING iteration (encoder -> (reward head, decoder + BCE,
 transition) x (horizon-2) -> backward -> clip -> Adam; reference main.py:143-297)
 on synthetic minipacman-shaped rollouts (64x64x3, horizon 10, A=5, R=2).
 
-  python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL all-reduce)
+  python bench.py --gpus N --steps K --warmup W [--config 1|2]
 
-Per-GPU batch is fixed at 64 (BASELINE.json configs[1]), so scaling is weak and
-`value` counts the frames of all ranks.  Inputs are resident in HBM before the
-timed region.  Prints ONE JSON line on rank 0.
+N > 1: one rank per GPU, RCCL all-reduce of the flat gradient buckets.  Either started by
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` (the ranks find
+RANK / LOCAL_RANK / WORLD_SIZE in the environment), or as a plain `python bench.py --gpus N`,
+which starts those N ranks itself (fresh child processes, before this process touches a GPU).
+
+Per-GPU batch is fixed at 64 (BASELINE.json configs[1]; 256 + the discriminator pass for
+--config 2 = configs[2]), so scaling is weak and `value` counts the frames of all ranks.
+Inputs are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,12 +36,23 @@ H = W = 64
 C, A, R, L = 3, 5, 2, 16      # BASELINE configs[1]; --size/--channels/--actions/--rewards select the other shapes
 
 
+ENC_GFLOP, TRANS_GFLOP, DEC_GFLOP, RP_GFLOP = 2.652, 6.540, 0.302, 0.0385     # forward, per sample
+
+
 def algorithmic_gflop_per_frame(horizon):
-    """SURVEY.md section 8d: 2*MAC, train = 3x forward, per predicted frame (64x64, C=3, A=5, R=2;
-    scaled by the pixel count for other sizes -- the C/A/R dependence is < 1 %)."""
-    enc = 2.652
-    step = 6.540 + 0.302 + 0.0385
-    return 3.0 * (enc + (horizon - 2) * step) / (horizon - 2) * (H * W) / 4096.0
+    """SURVEY.md section 8d's formula: 2*MAC, train = 3x forward for every unrolled step, per predicted
+    frame (64x64, C=3, A=5, R=2; scaled by the pixel count for other sizes -- the C/A/R dependence is < 1 %)."""
+    step = TRANS_GFLOP + DEC_GFLOP + RP_GFLOP
+    return 3.0 * (ENC_GFLOP + (horizon - 2) * step) / (horizon - 2) * (H * W) / 4096.0
+
+
+def executed_gflop_per_frame(horizon):
+    """What the iteration really executes (reference and this build alike): the output of the LAST transition
+    (t = horizon-2, main.py:207) is never consumed, so that call runs forward only -- (horizon-3) transitions
+    at 3x forward + one at 1x."""
+    n = horizon - 2
+    total = 3.0 * (ENC_GFLOP + n * (DEC_GFLOP + RP_GFLOP) + (n - 1) * TRANS_GFLOP) + TRANS_GFLOP
+    return total / n * (H * W) / 4096.0
 
 
 def build_nets(seed):
@@ -72,7 +90,7 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("SCM_BENCH_CPU_THREADS", "16"))))
 
 
-def cpu_baseline(seconds_budget=20.0):
+def cpu_baseline(seconds_budget=10.0):
     """Reference CPU path (the oracle: same arithmetic as the reference's torch-CPU
     modules, pinned to them by tests/test_oracle_golden.py) on BASELINE configs[0]:
     64x64, batch 8, horizon 5, timed on this box's host cores."""
@@ -168,12 +186,64 @@ def decoder_leg(dev, batch):
             "bound": "mfma (970 FLOP/B algorithmic intensity)"}
 
 
+def _sha16(path):
+    try:
+        return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
+def measured_traffic(kernel_name):
+    """HBM bytes per launch of the dominant kernel from the newest committed PMC pass
+    (profiles/round*_pmc*.json, written by tools/pmc_parse.py).  The number is only valid for
+    the kernel it was measured on: each file records the sha of the kernel's source file, and a
+    file whose sha no longer matches the tree is skipped -> traffic null rather than stale."""
+    import glob
+    src = {"h16": "conv3x3_h16.hip", "mfma": "conv3x3_mfma.hip"}["h16" if "h16" in kernel_name else "mfma"]
+    sha = _sha16(os.path.join(ROOT, "scm_gan_amd", "csrc", src))
+    want = "conv3x3_h16_kernel<1," if "h16" in kernel_name else "conv3x3_mfma_kernel<4, 2, 2, 0,"
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_pmc*.json")), reverse=True):
+        try:
+            pmc = json.load(open(f))
+        except Exception:
+            continue
+        if pmc.get("kernel_source_sha16", {}).get(src) != sha:
+            continue
+        for k, v in pmc.get("kernels", {}).items():
+            if want in k and "hbm_traffic_bytes" in v:
+                return {"bytes": v["hbm_traffic_bytes"], "kernel": k, "file": os.path.basename(f),
+                        "kernel_source_sha16": sha, "measured_at_commit": pmc.get("git_commit")}
+    return None
+
+
+def self_launch(gpus, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes
+    (torch.distributed.run), BEFORE this process makes any GPU call (counting devices does not
+    initialise the runtime), and exit with their status.  No exec, no fork of a GPU process."""
+    have = torch.cuda.device_count()
+    if have < gpus:
+        raise SystemExit("bench.py --gpus %d needs %d GPUs on this node, found %d" % (gpus, gpus, have))
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (BASELINE configs[1])")
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", type=int, default=1, choices=(1, 2),
+                    help="BASELINE.json configs index: 1 = batch 64, generator only (the headline); 2 = batch 256 + the "
+                         "spectral-normalised discriminator's forward / backward / Adam on (B,3,64,64) U{0,1} noise maps "
+                         "(SURVEY.md 8(d) cfg3; the reference defines no GAN loss, the critic term is build-defined)")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default 64 for --config 1, 256 for --config 2)")
     ap.add_argument("--horizon", type=int, default=10)
     ap.add_argument("--size", type=int, default=64, help="frame height = width (84: configs[3], 128: configs[4] shapes)")
     ap.add_argument("--channels", type=int, default=3)
@@ -190,33 +260,33 @@ def main():
                          "brackets): the run to put under rocprofv3 so its per-kernel averages match the bench's")
     a = ap.parse_args()
     global H, W, C, A, R
+    if a.batch is None:
+        a.batch = 256 if a.config == 2 else 64
     H = W = a.size
     C, A, R = a.channels, a.actions, a.rewards
-    headline = (a.size, a.channels, a.actions, a.rewards, a.batch, a.horizon, a.precision) == (64, 3, 5, 2, 64, 10, "fp32")
+    shape_ok = (a.size, a.channels, a.actions, a.rewards, a.horizon, a.precision) == (64, 3, 5, 2, 10, "fp32")
+    headline = shape_ok and a.config == 1 and a.batch == 64
+    cfg2 = shape_ok and a.config == 2 and a.batch == 256
     if a.profile_mode:
         a.no_kernel_timer = a.no_cpu_baseline = True
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from scm_gan_amd import dp
+    rank, local_rank, world, under_launcher = dp.env_world()
+    if not under_launcher and a.gpus > 1:
+        self_launch(a.gpus, sys.argv[1:])               # does not return
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % a.gpus)
-    torch.cuda.set_device(local_rank)
+        raise SystemExit("bench.py --gpus %d was started under a launcher with WORLD_SIZE=%d" % (a.gpus, world))
+    # one process per GPU, RCCL (backend "nccl" on ROCm); also taken for a 1-rank launch under
+    # torch.distributed.run so that path is exercised on a single-GPU box
+    rank, local_rank, world = dp.init_from_env("nccl" if under_launcher else None)
     dev = torch.device("cuda", local_rank)
-    under_launcher = "RANK" in os.environ and "MASTER_PORT" in os.environ
-    if world > 1 or under_launcher:
-        # one process per GPU, RCCL (backend "nccl" on ROCm); also taken for a 1-rank launch
-        # under torch.distributed.run so that path is exercised on a single-GPU box
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
 
     from scm_gan_amd import main as M, ops
     from scm_gan_amd.datasource import SyntheticDatasource
     ops.set_compute_precision(a.precision)
     opts = M.parser.parse_args(["--train-iters", str(a.steps + a.warmup), "--horizon-min", str(a.horizon),
-                                "--horizon-max", str(a.horizon), "--batch-size", str(a.batch)])
+                                "--horizon-max", str(a.horizon), "--batch-size", str(a.batch * world)]
+                               + (["--gan"] if a.config == 2 else []))
     enc, dec, rp, disc, tr = build_nets(0)          # identical replicas on every rank
     tr.seed_noise(1234 + rank)                      # rank-offset Philox stream
     trainer = M.Trainer(L, A, R, enc, dec, rp, disc, tr, opts)
@@ -226,7 +296,7 @@ def main():
     def barrier():
         if world > 1 or under_launcher:
             import torch.distributed as dist
-            dist.barrier()
+            dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
     for i in range(a.warmup):
@@ -258,30 +328,42 @@ def main():
             "dtype": "f32" if a.precision == "fp32" else "f16 fwd / bf16 bwd MFMA operands, f32 accumulate + f32 tensors",
             "data": "synthetic",
             "config": {"workload": "%s: %dx%dx%d frames, per-GPU batch %d, horizon %d, A=%d, R=%d, "
-                                   "training iteration fwd+bwd+clip+Adam, reference loss (BCE + reward MSE), no "
-                                   "discriminator" % ("configs[1] minipacman-shaped" if headline else
-                                                      ("non-headline shape" if a.precision == "fp32" else
-                                                       "NON-HEADLINE opt-in 16-bit MFMA operands"),
-                                                      H, W, C, a.batch, a.horizon, A, R),
-                       "global_batch": a.batch * world, "horizon": a.horizon, "parallelism": "dp%d" % world},
+                                   "training iteration fwd+bwd+clip+Adam, reference loss (BCE + reward MSE), %s"
+                                   % ("configs[1] minipacman-shaped" if headline else
+                                      "configs[2] minipacman-shaped" if cfg2 else
+                                      ("non-headline shape" if a.precision == "fp32" else
+                                       "NON-HEADLINE opt-in 16-bit MFMA operands"),
+                                      H, W, C, a.batch, a.horizon, A, R,
+                                      "no discriminator" if a.config == 1 else
+                                      "+ spectral-normalised discriminator fwd/bwd/Adam on (B,3,64,64) U{0,1} noise maps "
+                                      "(the reference constructs it, models.py:195-223 / main.py:76,128, but defines NO "
+                                      "GAN loss: the critic term, the mean logit, is build-defined)"),
+                       "global_batch": a.batch * world, "horizon": a.horizon, "parallelism": "dp%d" % world,
+                       "grad_allreduce": ("none (1 rank)" if world == 1 and not under_launcher else
+                                          "RCCL SUM of 4 flat fp32 buckets; decoder/transition/reward-head%s buckets issued "
+                                          "from a hook on the first latent's gradient, under the encoder's backward"
+                                          % ("/discriminator" if a.config == 2 else ""))},
+            # two FLOP counts, both 2*MAC with no credit for padding or recompute:
+            #   algorithmic = SURVEY.md 8(d)'s formula (3x forward for every unrolled step);
+            #   executed    = the same minus the backward of the last transition, whose output nothing consumes
+            #                 (reference main.py:207 at t = horizon-2) -- what the GPU really ran.
             "algorithmic_tflops": value * algorithmic_gflop_per_frame(a.horizon) / 1e3,
+            "executed_tflops": value * executed_gflop_per_frame(a.horizon) / 1e3,
+            "executed_frac_of_f32_mfma_peak": (value / world * executed_gflop_per_frame(a.horizon) / 1e3 / PEAK_F32_MFMA_TFLOPS
+                                               if a.precision == "fp32" else None),
         }
         if timer is not None:
             summ = timer.summary()
             dom = max(summ.items(), key=lambda kv: kv[1]["ms"])
             name, s = dom
             achieved = s["flops"] / (s["ms"] * 1e-3) / 1e12
-            traffic = None       # HBM bytes per launch from the committed PMC passes (profiles/round1_pmc2.json)
-            try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc2.json")))["kernels"]
-                want = "conv3x3_h16_kernel<1," if "h16" in name else "conv3x3_mfma_kernel<4, 2, 2, 0,"
-                key = [k for k in pmc if want in k]
-                traffic = pmc[key[0]]["hbm_traffic_bytes"] if key else None
-            except Exception:
-                pass
+            # HBM bytes per launch: a PMC measurement (separate rocprofv3 --pmc passes, tools/prof_hot2.py) cited
+            # from profiles/, valid only while the kernel's source is the one it was measured on (else null)
+            tr_info = measured_traffic(name)
             peak = PEAK_F32_MFMA_TFLOPS if "h16" not in name else PEAK_F16_MFMA_TFLOPS
             out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": peak,
-                               "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+                               "unit": "TFLOP/s", "frac": achieved / peak,
+                               "traffic": tr_info["bytes"] if tr_info else None, "traffic_source": tr_info,
                                "launches": s["launches"], "avg_launch_us": s["ms"] * 1e3 / s["launches"],
                                "share_of_step": s["ms"] / (dt * 1e3)}
             out["kernels"] = {k: {"launches": v["launches"], "ms_total": round(v["ms"], 3),
@@ -295,9 +377,7 @@ def main():
             if not a.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
-    if world > 1 or under_launcher:
-        import torch.distributed as dist
-        dist.destroy_process_group()
+    dp.shutdown()
 
 
 if __name__ == "__main__":

@@ -16,6 +16,20 @@ class TimeSeries(object):
     def collect(self, name, value):
         self.series.setdefault(name, []).append(value.detach() if hasattr(value, 'detach') else value)
 
+    def all_reduce_latest(self, world):
+        """Data parallel: replace the latest value of every series by its mean over the ranks
+        (one small all-reduce at print time; every rank must call it with the same series)."""
+        import torch
+        import torch.distributed as dist
+        names = sorted(k for k, v in self.series.items() if v and hasattr(v[-1], 'detach'))
+        if not names:
+            return
+        packed = torch.stack([self.series[k][-1].detach().reshape(()).float() for k in names])
+        dist.all_reduce(packed, op=dist.ReduceOp.SUM)
+        packed = packed / world
+        for i, k in enumerate(names):
+            self.series[k][-1] = packed[i]
+
     def _latest(self):
         return {k: float(v[-1]) for k, v in self.series.items() if v}
 

@@ -20,6 +20,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from . import dp
 from . import models
 from . import ops
 from .datasource import allocate_datasource
@@ -61,6 +62,15 @@ parser.add_argument('--prefetch', type=int, default=0,
                          'double-buffered uploads, on-device one-hot); 0 = the reference\'s serial loop')
 parser.add_argument('--eval-every', type=int, default=2000, help='Evaluate + checkpoint cadence (ITERS_PER_VIDEO)')
 parser.add_argument('--log-every', type=int, default=10)
+parser.add_argument('--gan', action='store_true',
+                    help='BASELINE configs[2]: also run the spectral-normalised discriminator forward / backward / Adam every '
+                         'iteration on (B, 3, 64, 64) U{0,1} noise maps (SURVEY.md 8(d) cfg3). The reference constructs the '
+                         'discriminator and its optimizer (main.py:76,128) but defines NO GAN loss; the critic term here '
+                         '(mean logit) is build-defined')
+parser.add_argument('--no-overlap', action='store_true',
+                    help='data parallel: all-reduce every bucket after backward() instead of overlapping with it')
+parser.add_argument('--check-replicas', action='store_true',
+                    help='data parallel: verify after every evaluation that all ranks hold identical weights and u / v')
 
 # The reference parses sys.argv at import (main.py:51); here the module-level
 # `args` holds the defaults and main() replaces it, so the API is importable.
@@ -119,36 +129,8 @@ def decoder_pixel_loss(target, predicted_logits):
     return ops.pixel_bce(predicted_logits, target)
 
 
-class _FlatGrads(object):
-    """Gradients of one network as views of a single flat fp32 buffer: one
-    all-reduce per network, no pack/unpack kernels."""
-
-    def __init__(self, module):
-        self.params = [p for p in module.parameters() if p.requires_grad]
-        n = sum(p.numel() for p in self.params)
-        self.flat = torch.zeros(n, device=self.params[0].device, dtype=torch.float32)
-        o = 0
-        for p in self.params:
-            p.grad = self.flat[o:o + p.numel()].view_as(p)
-            o += p.numel()
-
-    def zero(self):
-        self.flat.zero_()
-        for p in self.params:       # restore views if something replaced .grad
-            if p.grad is None or p.grad.data_ptr() < self.flat.data_ptr() or \
-                    p.grad.data_ptr() >= self.flat.data_ptr() + 4 * self.flat.numel():
-                raise RuntimeError("flat gradient view was replaced")
-
-    def all_reduce(self):
-        import torch.distributed as dist
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-
-
-def _dist():
-    import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized():
-        return dist.get_rank(), dist.get_world_size()
-    return 0, 1
+_FlatGrads = dp.FlatGrads        # (kept under the round-1 names: tests import them)
+_dist = dp.world_info
 
 
 class Trainer(object):
@@ -172,15 +154,29 @@ class Trainer(object):
         self.opt_trans = AdamClip(transition.parameters(), lr=lr, clip_value=0.1)
         self.opt_disc = AdamClip(discriminator.parameters(), lr=lr)
         self.opt_pred = AdamClip(reward_predictor.parameters(), lr=lr)
-        self.flats = [_FlatGrads(m) for m in (encoder, decoder, transition, reward_predictor)]
-        for o in (self.opt_enc, self.opt_dec, self.opt_trans, self.opt_pred):
+        self.gan = bool(getattr(self.a, 'gan', False))
+        self.flat_enc = dp.FlatGrads(encoder, 'encoder')
+        # complete once the gradient of the first encoder output exists (dp.GradSync)
+        self.flats_early = [dp.FlatGrads(decoder, 'decoder'), dp.FlatGrads(transition, 'transition'),
+                            dp.FlatGrads(reward_predictor, 'reward_predictor')]
+        if self.gan:
+            self.flats_early.append(dp.FlatGrads(discriminator, 'discriminator'))
+        self.flats = [self.flat_enc] + self.flats_early
+        for o in (self.opt_enc, self.opt_dec, self.opt_trans, self.opt_pred, self.opt_disc):
             o.grad_scale = 1.0 / self.world
+        force = os.environ.get("SCM_FORCE_ALLREDUCE") == "1"
+        overlap = not getattr(self.a, 'no_overlap', False)
+        self.sync = dp.GradSync(self.flats_early if overlap else [], [self.flat_enc] if overlap else self.flats,
+                                enabled=self.world > 1 or force)
         self.ts = TimeSeries('Training Model', self.a.train_iters, tensorboard=True)
         self.side_stream = torch.cuda.Stream()
+        self._disc_half = None
+        self._disc_noise_offset = 0
 
-    def step(self, states, rewards, dones, onehots, theta, train_iter=1, actions=None):
+    def step(self, states, rewards, dones, onehots, theta, train_iter=1, actions=None, disc_noise=None):
         """states (B,T,C,H,W), rewards (B,T,R), dones (B,T) as 0/1 floats, onehots
-        (B,T,A): fp32 device tensors.  Returns the (device) loss."""
+        (B,T,A): fp32 device tensors; disc_noise: optional (B,3,64,64) U{0,1} maps for the
+        --gan discriminator pass (drawn on the device otherwise).  Returns the (device) loss."""
         a = self.a
         ts = self.ts
         encoder, decoder, reward_predictor, transition = self.encoder, self.decoder, self.reward_predictor, \
@@ -196,15 +192,18 @@ class Trainer(object):
             f.zero()
 
         # SpectralNorm power iterations depend on the weights only: the encoder's three
-        # run in one launch, and the (horizon-2) x 5 of the unrolled transition run
-        # on a side stream underneath the encoder's convolutions.
-        SN.precompute([encoder], 1)
+        # (and the discriminator's two) run in one launch, and the (horizon-2) x 5 of the
+        # unrolled transition run on a side stream underneath the encoder's convolutions.
+        # Sigmas an aborted iteration left queued are dropped first.
+        SN.clear_precomputed([encoder, transition, self.discriminator])
+        SN.precompute([encoder] + ([self.discriminator] if self.gan else []), 1)
         main_stream = torch.cuda.current_stream()
         self.side_stream.wait_stream(main_stream)
         with torch.cuda.stream(self.side_stream):
             SN.precompute([transition], prediction_horizon - 2)
 
         z = encoder(states[:, 0:3])                                            # main.py:162
+        self.sync.arm(z)
         main_stream.wait_stream(self.side_stream)
         targets = states.transpose(0, 1).contiguous()      # (T, B, C, H, W): targets[t] is one contiguous frame batch
         z_orig = z.clone() if (enable_cf_shuffle_loss or enable_control_bias_loss) else None
@@ -250,18 +249,39 @@ class Trainer(object):
             loss = loss + cf_loss
             ts.collect('CF Control Bias Loss', cf_loss)
 
-        loss.backward()                                                        # main.py:285
+        if self.gan:
+            d_loss = self._discriminator_loss(batch_size, disc_noise)
+            ts.collect('D mean logit', d_loss)
 
-        if self.world > 1 or os.environ.get("SCM_FORCE_ALLREDUCE") == "1":
-            for f in self.flats:
-                f.all_reduce()      # sum over ranks; AdamClip applies 1/world before the clip
+        with ops.grad_sinks():             # weight / bias gradients accumulate straight into the flat buckets
+            torch.autograd.backward([loss, d_loss] if self.gan else [loss])    # main.py:285
+
+        # data parallel: SUM over ranks (the early buckets were issued from the hook on z, under the encoder's
+        # backward); AdamClip applies 1/world before the clip, so N ranks x B/N equal one rank x B
+        self.sync.finish()
 
         self.opt_pred.step()                                                   # main.py:292-296
         if not a.finetune_reward:
             self.opt_enc.step()
             self.opt_dec.step()
             self.opt_trans.step()
+        if self.gan:
+            self.opt_disc.step()
         return loss.detach()
+
+    def _discriminator_loss(self, batch_size, noise=None):
+        """BASELINE configs[2] / SURVEY.md 8(d) cfg3: the discriminator (models.py:195-223) forward on
+        (B, NOISE_DIM, 64, 64) maps of U{0,1} noise; its backward and Adam step follow with the rest of
+        the iteration.  The reference never forwards its discriminator and has no GAN loss
+        (main.py:76,128): the scalar trained on, the mean logit, is build-defined."""
+        if noise is None:
+            shape = (batch_size, models.NOISE_DIM, 64, 64)     # the only size fc1 accepts: 64 -> 31 -> 15 -> 7
+            if self._disc_half is None or self._disc_half.shape != shape:
+                self._disc_half = torch.full(shape, 0.5, device=_device())
+            seed = getattr(self.transition, 'noise_seed', 0) + 7919          # rank-offset like the latent noise
+            noise = ops.bernoulli_sample(self._disc_half, seed, self._disc_noise_offset)
+            self._disc_noise_offset += (self._disc_half.numel() + 3) // 4
+        return ops.mean_all(self.discriminator(noise))
 
 
     def _rollout_counterfactual(self, z_start, step_onehots):
@@ -300,13 +320,17 @@ class Trainer(object):
 
 def train(latent_dim, datasource, num_actions, num_rewards,
           encoder, decoder, reward_predictor, discriminator, transition):
-    """main.py:106-299."""
-    batch_size = args.batch_size
+    """main.py:106-299.  Under torch.distributed (one process per GPU) --batch-size is the GLOBAL
+    batch: every rank draws batch_size / world trajectories from its own datasource stream."""
     train_iters = args.train_iters
     trainer = Trainer(latent_dim, num_actions, num_rewards, encoder, decoder, reward_predictor, discriminator,
                       transition)
-    rank = trainer.rank
+    rank, world = trainer.rank, trainer.world
+    if args.batch_size % world:
+        raise ValueError("--batch-size %d does not split evenly over %d ranks" % (args.batch_size, world))
+    batch_size = args.batch_size // world
     ts = trainer.ts
+    nets = [encoder, decoder, transition, discriminator, reward_predictor]
 
     def horizon_of(it):                                                        # main.py:143-145
         return args.horizon_min + int((args.horizon_max - args.horizon_min) * (it / train_iters))
@@ -317,10 +341,14 @@ def train(latent_dim, datasource, num_actions, num_rewards,
                                  num_actions, depth=args.prefetch)
     for train_iter in range(args.start_iter, train_iters + 1):
         if train_iter % args.eval_every == 0:
+            # EVERY rank evaluates: SpectralNorm advances u / v on every forward, eval included
+            # (spectral_normalization.py:66-68), and the iteration depends on the weights only -- so the
+            # replicas stay bit-identical only if all of them make the same calls.  Rank 0 writes.
+            evaluate(datasource, encoder, decoder, transition, discriminator, reward_predictor, latent_dim,
+                     train_iter=train_iter, quiet=rank != 0)
+            if world > 1 and args.check_replicas:
+                dp.assert_replicas_identical(nets, 'after the evaluation at iteration %d' % train_iter)
             if rank == 0:
-                print('Evaluating networks...')
-                evaluate(datasource, encoder, decoder, transition, discriminator, reward_predictor, latent_dim,
-                         train_iter=train_iter)
                 print('Saving networks to filesystem...')
                 torch.save(transition.state_dict(), 'model-transition.pth')
                 torch.save(encoder.state_dict(), 'model-encoder.pth')
@@ -339,6 +367,8 @@ def train(latent_dim, datasource, num_actions, num_rewards,
             states, rewards, dones, actions = datasource.get_trajectories(batch_size, prediction_horizon)
             trainer.step(_upload(states), _upload(rewards), _upload(np.asarray(dones).astype(int)),
                          onehot(actions, num_actions), theta, train_iter, actions)
+        if world > 1 and train_iter % args.log_every == 0:
+            ts.all_reduce_latest(world)        # the logged losses are local-batch means: average them over the ranks
         if rank == 0:
             ts.print_every(args.log_every)
     if rank == 0:
@@ -348,12 +378,15 @@ def train(latent_dim, datasource, num_actions, num_rewards,
 
 
 def evaluate(datasource, encoder, decoder, transition, discriminator, reward_predictor, latent_dim, train_iter=0,
-             use_training_set=False):
-    """main.py:315-322 (numeric part; the visualisers are out of scope)."""
-    print('Evaluating networks...')
+             use_training_set=False, quiet=False):
+    """main.py:315-322 (numeric part; the visualisers are out of scope).  quiet: compute only
+    (ranks other than 0 of a data-parallel job), no prints, no files."""
+    if not quiet:
+        print('Evaluating networks...')
     test_mode([encoder, decoder, transition, discriminator, reward_predictor])
     return measure_prediction_mse(datasource, encoder, decoder, transition, reward_predictor, train_iter,
-                                  num_factors=latent_dim, use_training_set=use_training_set)
+                                  num_factors=latent_dim, use_training_set=use_training_set, write_files=not quiet,
+                                  quiet=quiet)
 
 
 def compute_rollout_reward(z, transition, reward_predictor, num_actions,
@@ -445,13 +478,14 @@ def play(latent_dim, datasource, num_actions, num_rewards, encoder, decoder, rew
 @torch.no_grad()
 def measure_prediction_mse(datasource, encoder, decoder, transition, reward_pred,
                            train_iter=0, timesteps=100, num_factors=16, experiment_name='default',
-                           use_training_set=False, batch_size=100, write_files=True):
+                           use_training_set=False, batch_size=100, write_files=True, quiet=False):
     """main.py:784-855: open-loop eval rollout, per-step masked pixel / reward MSE.
     Returns {'pixel': (means, stds), 'reward': (means, stds)} and, like the
     reference's plot_error_graph (main.py:858-865), writes the mse_*.json files.
     Runs under no_grad: the reference cuts the graph every step anyway (z.detach_(),
     main.py:835) and SpectralNorm advances u/v regardless of grad mode."""
     start_time = time.time()
+    say = (lambda *a: None) if quiet else print
     num_actions = datasource.binary_input_channels
     states, rewards, dones, actions = datasource.get_trajectories(batch_size=batch_size, timesteps=timesteps,
                                                                   training=use_training_set)
@@ -467,7 +501,7 @@ def measure_prediction_mse(datasource, encoder, decoder, transition, reward_pred
     for t in range(2, timesteps):
         active_mask = active_mask * (1 - dones[:, t])
         if float(active_mask.sum()) == 0:
-            print('Ending simulation at max trajectory length {}'.format(t))
+            say('Ending simulation at max trajectory length {}'.format(t))
             break
         diffs = active_mask * ops.pixel_mse(decoder(z), states[:, t])
         scale = batch_size / torch.sum(active_mask)
@@ -481,12 +515,12 @@ def measure_prediction_mse(datasource, encoder, decoder, transition, reward_pred
         z = transition(z, onehots[:, t])
         z = z.detach()
     if len(mse_losses) == 0:
-        print('Degenerate trajectory, skipping MSE calculation')
+        say('Degenerate trajectory, skipping MSE calculation')
         return None
-    print('MSE over {} timesteps: min {:.3f} max {:.3f}'.format(timesteps, min(mse_losses), max(mse_losses)))
-    print(sparkline(mse_losses, length=80))
-    print('Avg. MSE loss: {}'.format(np.mean(mse_losses)))
-    print('Finished trajectory simulation in {:.02f}s'.format(time.time() - start_time))
+    say('MSE over {} timesteps: min {:.3f} max {:.3f}'.format(timesteps, min(mse_losses), max(mse_losses)))
+    say(sparkline(mse_losses, length=80))
+    say('Avg. MSE loss: {}'.format(np.mean(mse_losses)))
+    say('Finished trajectory simulation in {:.02f}s'.format(time.time() - start_time))
     if write_files:
         for name, (m, s) in (('pixel', (mse_losses, mse_stddevs)), ('reward', (reward_losses, reward_stddevs))):
             with open('mse_{}_iter_{:06d}.json'.format(name, train_iter), 'w') as fp:
@@ -500,10 +534,13 @@ def main(argv=None):
     """main.py:64-103."""
     global args
     args = parser.parse_args(argv)
+    # one process per GPU: bind cuda:LOCAL_RANK and join the process group BEFORE any other GPU call
+    rank, local_rank, world = dp.init_from_env()
     ops.set_compute_precision(args.precision)
-    torch.manual_seed(args.seed)
+    torch.manual_seed(args.seed)                   # identical initial replicas on every rank
     latent_dim = 16
-    datasource = allocate_datasource(args.env, seed=args.seed)
+    rank_seed = args.seed + dp.SEED_STRIDE * rank  # per-rank data stream and latent-noise stream
+    datasource = allocate_datasource(args.env, seed=rank_seed)
     num_actions = datasource.binary_input_channels
     num_rewards = datasource.scalar_output_channels
     encoder = models.Encoder(latent_dim, datasource.conv_input_channels)
@@ -511,9 +548,10 @@ def main(argv=None):
     reward_predictor = models.RewardPredictor(latent_dim, num_rewards)
     discriminator = models.Discriminator()
     transition = models.Transition(latent_dim, num_actions)
-    transition.seed_noise(args.seed)
+    transition.seed_noise(rank_seed)
     if args.load_from is None:
-        print('No --load-from directory specified: initializing new networks')
+        if rank == 0:
+            print('No --load-from directory specified: initializing new networks')
     elif 'model-encoder.pth' not in os.listdir(args.load_from):
         raise ValueError('Failed to load weights from *.pth')
     else:
@@ -522,6 +560,9 @@ def main(argv=None):
                           (discriminator, 'discriminator'), (reward_predictor, 'reward_predictor')):
             net.load_state_dict(torch.load(os.path.join(args.load_from, 'model-{}.pth'.format(name)),
                                            weights_only=True))
+    if world > 1:
+        # whatever the ranks initialised or loaded, rank 0's parameters and u / v are THE replica
+        dp.broadcast_replica([encoder, decoder, transition, discriminator, reward_predictor])
     if args.evaluate:
         # main.py:92-99: play-throughs with the model-predictive agent (datasources that can make_env), then the
         # open-loop prediction error
@@ -540,7 +581,9 @@ def main(argv=None):
     else:
         train(latent_dim, datasource, num_actions, num_rewards, encoder, decoder, reward_predictor, discriminator,
               transition)
-    print('Finished execution, terminating')
+    if rank == 0:
+        print('Finished execution, terminating')
+    dp.shutdown()
 
 
 if __name__ == '__main__':

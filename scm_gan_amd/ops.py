@@ -192,14 +192,28 @@ def _sn_fold(g, weight_bar, u, v, inv_sigma, dot_part=None, into=None):
     return out
 
 
-# When a parameter already owns a contiguous .grad buffer (Trainer's flat buckets), the
-# backward kernels accumulate into it directly and hand autograd no gradient for that
-# parameter: saves one elementwise add launch per parameter per timestep.
-accumulate_in_kernel = True
+# Inside `with grad_sinks():` (Trainer.step's backward), a parameter that already owns a
+# contiguous fp32 .grad buffer (the flat buckets) gets its weight / bias gradients accumulated
+# into that buffer by the backward kernels themselves, and autograd is handed no gradient for
+# it: saves one elementwise add launch per parameter per timestep.  Off by default, so
+# torch.autograd.grad(), backward(inputs=...) and parameter hooks keep their meaning.
+_sinks_on = [False]
+
+
+class grad_sinks(object):
+    def __init__(self, on=True):
+        self.on = on
+
+    def __enter__(self):
+        self.prev = _sinks_on[0]
+        _sinks_on[0] = self.on
+
+    def __exit__(self, *exc):
+        _sinks_on[0] = self.prev
 
 
 def _grad_sink(param):
-    if not accumulate_in_kernel or param is None or not isinstance(param, torch.nn.Parameter):
+    if not _sinks_on[0] or param is None or not isinstance(param, torch.nn.Parameter):
         return None
     g = param.grad
     if g is None or not g.is_contiguous() or g.dtype != torch.float32 or not g.is_cuda:
@@ -296,9 +310,11 @@ class Conv3x3Fn(Function):
                                                 c1 + c2, _p(d_act), _p(dw_eff), _stream()), "scm_action_bias_bwd")
             if inv_sigma is not None:
                 dw = _sn_fold(dw_eff, w, u, v, inv_sigma, dot_part, into=w_sink)
+                sunk_w = w_sink is not None
             else:
                 dw = dw_eff
-            if w_sink is not None:
+                sunk_w = direct_w
+            if sunk_w:
                 dw = None                # already accumulated into weight.grad
             if b_sink is not None:
                 db = None
@@ -370,6 +386,16 @@ def threshold(p):
     p = _chk(p.detach(), "threshold")
     out = torch.empty_like(p)
     L.check(L.lib().scm_bernoulli(_p(p), None, _p(out), p.numel(), 0, 0, 0, _stream()), "scm_bernoulli")
+    return out
+
+
+def bernoulli_sample(p, seed, offset):
+    """(philox(seed, offset) < p) without a gradient: the U{0,1} noise maps the discriminator
+    is fed (models.py:18,193-199) are bernoulli_sample(0.5)."""
+    p = _chk(p.detach(), "bernoulli_sample")
+    out = torch.empty_like(p)
+    L.check(L.lib().scm_bernoulli(_p(p), None, _p(out), p.numel(), 2, int(seed), int(offset), _stream()),
+            "scm_bernoulli")
     return out
 
 
@@ -475,6 +501,20 @@ class LinearFn(Function):
         return dx, dw, db, None
 
 
+_mean_weights = {}
+
+
+def mean_all(x):
+    """Mean over every element of x as a 0-dim tensor (differentiable): a 1 x n linear
+    layer with constant weights 1/n on the linear kernel."""
+    n = x.numel()
+    key = (n, x.device)
+    w = _mean_weights.get(key)
+    if w is None:
+        w = _mean_weights[key] = torch.full((1, n), 1.0 / n, device=x.device, dtype=torch.float32)
+    return LinearFn.apply(x.reshape(1, n), w, None, ACT_NONE).reshape(())
+
+
 class CoordCatFn(Function):
     """cat([x, coord_x, coord_y], 1), coordconv.py:12-14."""
 
@@ -572,7 +612,11 @@ class StepLossFn(Function):
         lib = L.lib()
         rhat, bce, mask_in = _chk(rhat, "step_loss"), _chk(bce, "step_loss"), _chk(mask_in, "step_loss")
         B, R = rhat.shape
-        assert rewards_t.stride(1) == 1 and rewards_t.is_cuda and dones_t.is_cuda
+        for name, t in (("rewards_t", rewards_t), ("dones_t", dones_t)):
+            if not t.is_cuda or t.dtype != torch.float32:
+                raise RuntimeError("scm_gan_amd.step_loss: %s must be an fp32 GPU tensor (got %s on %s)"
+                                   % (name, t.dtype, t.device))
+        assert rewards_t.stride(1) == 1
         loss_out, rd_rec = _new(rhat, 1), _new(rhat, 2)
         mask_out = _new(rhat, B)
         lin = None if loss_in is None else _chk(loss_in, "step_loss")

@@ -55,8 +55,12 @@ class SpectralNorm(nn.Module):
         w = getattr(self.module, self.name + "_bar")
         sigma = inv_sigma = None
         if self._precomputed:
-            sigma, inv_sigma = self._precomputed.pop(0)
-            return w, u, v, sigma, inv_sigma
+            stamp, sigma, inv_sigma = self._precomputed.pop(0)
+            if stamp == _stamp(w):
+                return w, u, v, sigma, inv_sigma
+            # W_bar changed (optimizer step, load_state_dict) since precompute(): the queued sigmas belong
+            # to the old weights.  u / v have already advanced past them; drop the rest and iterate live.
+            self._precomputed = []
         for _ in range(self.power_iterations):
             sigma, inv_sigma = ops.sn_power_iter(w, u, v)
         return w, u, v, sigma, inv_sigma
@@ -70,22 +74,39 @@ class SpectralNorm(nn.Module):
         return self.module.forward(*args, _sn=(w, u, v, inv_sigma), **kwargs)
 
 
+def _stamp(w):
+    """Identity of the W_bar a queued sigma was computed from."""
+    return (ops.weights_epoch(), w._version, w.data_ptr())
+
+
+def _spectral_norms(modules):
+    sns = []
+    for m in modules:
+        sns += [x for x in m.modules() if isinstance(x, SpectralNorm)]
+    return sns
+
+
+def clear_precomputed(modules):
+    """Drop sigmas queued by precompute() and not consumed (an iteration that raised midway)."""
+    for x in _spectral_norms(modules):
+        x._precomputed = []
+
+
 def precompute(modules, calls):
     """Run the power iterations of the next `calls` forward calls of every
     SpectralNorm found in `modules`, batched: the iteration depends only on
     (W_bar, u, v), never on the data, so all of an unrolled rollout's iterations
     can run ahead of it in one launch per 8 layers (u, v end in the same state and
     every call still sees its own sigma).  Results are queued per module and
-    consumed by the following forward calls; valid only while W_bar is unchanged."""
-    sns = []
-    for m in modules:
-        sns += [x for x in m.modules() if isinstance(x, SpectralNorm) and x.power_iterations == 1
-                and x.name == 'weight']
+    consumed by the following forward calls; each entry carries the identity of the W_bar
+    it was computed from and is dropped when that no longer matches."""
+    sns = [x for x in _spectral_norms(modules) if x.power_iterations == 1 and x.name == 'weight']
     for i in range(0, len(sns), 8):
         group = sns[i:i + 8]
         layers = [(getattr(x.module, "weight_bar"), getattr(x.module, "weight_u"), getattr(x.module, "weight_v"))
                   for x in group]
         out = ops.sn_power_iter_multi(layers, calls)
         for k, x in enumerate(group):
-            x._precomputed += [(out[k, 0, c:c + 1], out[k, 1, c:c + 1]) for c in range(calls)]
+            stamp = _stamp(layers[k][0])
+            x._precomputed += [(stamp, out[k, 0, c:c + 1], out[k, 1, c:c + 1]) for c in range(calls)]
     return len(sns)
