@@ -486,6 +486,7 @@ class LinearFn(Function):
         y = _new(x, B, nout)
         L.check(L.lib().scm_linear(_p(x), _p(w), _p(bias), B, nin, nout, act, _p(y), _stream()), "scm_linear")
         ctx.act = act
+        ctx.has_bias = bias is not None
         ctx.save_for_backward(x, w, y)
         return y
 
@@ -498,7 +499,7 @@ class LinearFn(Function):
         dx, dw, db = torch.empty_like(x), torch.empty_like(w), _new(gy, nout)
         L.check(L.lib().scm_linear_bwd(_p(x), _p(w), _p(y), _p(gy), B, nin, nout, ctx.act, _p(dx), _p(dw), _p(db),
                                        _stream()), "scm_linear_bwd")
-        return dx, dw, db, None
+        return dx, dw, (db if ctx.has_bias else None), None
 
 
 _mean_weights = {}
