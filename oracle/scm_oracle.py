@@ -343,6 +343,30 @@ def compute_rollout_reward(z, tr, rp, num_actions, lookahead=2, rollout_depth=12
         return cum.sum(dim=1).max(dim=0)[0], cum
 
 
+def excitation_backtrack(tr, rp, z0, num_actions, noises, steps=30, threshold=0.8, first_action=1, later_action=3):
+    """Numeric core of excitation_bptt.visualize_bptt, excitation_bptt.py:6-53: train-mode rollout
+    (straight-through sampler, explicit noise) keeping gradients on every z_t and one-hot a_t; once
+    |sum r| > threshold, backward from the arg-max pixel of the reward map (:36-37).
+    Returns None or {'t', 'rewards', 'a', 'a_grad', 'z_grad', 'z0_grad'}."""
+    z = z0.clone().requires_grad_(True)
+    z_start = z
+    acts, zees, rewards = [], [], []
+    for t in range(steps):
+        a = onehot(first_action if t == 0 else later_action, num_actions).unsqueeze(0).clone().requires_grad_(True)
+        acts.append(a)
+        z = transition_forward(tr, z, a, True, noises[t])
+        z.retain_grad()
+        zees.append(z)
+        r, rmap = reward_forward(rp, z, visualize=True)
+        rewards.append(r.detach().clone())
+        if float(r.detach().sum().abs()) > threshold:
+            peak = (rmap.abs() == rmap.abs().max()).to(rmap.dtype)
+            (rmap * peak).sum().backward()
+            return {"t": t, "rewards": rewards, "a": [x.detach() for x in acts], "a_grad": [x.grad for x in acts],
+                    "z_grad": [x.grad for x in zees], "z0_grad": z_start.grad}
+    return None
+
+
 def clone_state(np_state):
     """numpy state dict (tests/golden/weights.py) -> fresh torch state."""
     return {k: torch.from_numpy(np.array(v)).clone() for k, v in np_state.items()}

@@ -27,7 +27,7 @@ def excitation_backtrack(z, transition, reward_predictor, num_actions, steps=30,
         z.retain_grad()
         zees.append(z)
         r, rmap = reward_predictor(z, visualize=True)
-        if float(r.sum().abs()) > threshold:
+        if float(r.detach().sum().abs()) > threshold:
             peak = (rmap.abs() == rmap.abs().max()).to(rmap.dtype)      # excitation_bptt.py:36
             (rmap * peak).sum().backward()
             return {

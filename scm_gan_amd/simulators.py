@@ -1,9 +1,10 @@
 """The reference's three pure-numpy simulators as batch datasources.
 
-Restated from the behaviour of /root/reference/envs/{gridworld,gameoflife,betterpong}.py;
-PARITY UNPINNED: those modules import gym, which is not available here, so they cannot be
-run to produce fixtures -- the dynamics below follow a reading of their source and are
-checked by rule tests (tests/test_host_logic.py), not against reference output.
+Restated from the behaviour of /root/reference/envs/{gridworld,gameoflife,betterpong}.py and
+pinned to them: tests/golden/envs.npz holds (state, action) -> (next state, reward, done, frame)
+cases produced by the reference modules themselves (imported behind a stub of
+gym.spaces.discrete.Discrete, tests/golden/make_golden.py gen_envs); tests/test_simulators_golden.py
+requires exact equality, tests/test_host_logic.py adds rule tests.
 
 Design differences, deliberate:
   * one vectorised state per batch (arrays over B) instead of B Python objects behind a
@@ -28,12 +29,16 @@ from .datasource import Datasource
 
 def _fill_rects(frames, channel, cx, cy, half_w, half_h):
     """frames[b, channel, top:bottom, left:right] = 1 with the reference's clipping
-    (envs/gridworld.py:62-68): left/top clipped at 0, right/bottom at size-1, end-exclusive."""
+    (envs/gridworld.py:62-68): left/top clipped at 0, right/bottom at size-1, end-exclusive.
+    The ends are Python slice stops: a negative one (a rectangle wholly left of / above the frame,
+    not reachable in play) counts from the far edge, as in the reference."""
     B, _, H, W = frames.shape
     left = np.maximum(cx - half_w, 0)
     right = np.minimum(cx + half_w, W - 1)
+    right = np.where(right < 0, np.maximum(right + W, 0), right)
     top = np.maximum(cy - half_h, 0)
     bottom = np.minimum(cy + half_h, H - 1)
+    bottom = np.where(bottom < 0, np.maximum(bottom + H, 0), bottom)
     cols = np.arange(W)[None, :]
     rows = np.arange(H)[None, :]
     in_x = (cols >= left[:, None]) & (cols < right[:, None])          # (B, W)

@@ -15,7 +15,12 @@ unmodified, behind an in-process shim:
      padding=1: torch <= 1.4, which the reference was written for, padded
      (p+1)//2 = 1 pixel per side for that call (SURVEY.md section 0.5);
   4. torch.bernoulli(p) is replaced by (u < p) with u drawn from a recorded
-     numpy stream, so the sampled latents can be reproduced on the device.
+     numpy stream, so the sampled latents can be reproduced on the device;
+  5. for the pure-numpy games (envs/gridworld.py, gameoflife.py, betterpong.py): a stub
+     `gym.spaces.discrete.Discrete` (the only thing they use from gym) and
+     `np.float = float` (removed from numpy 2.x; gameoflife.py:44 calls astype(np.float));
+  6. tensor.type(torch.cuda.FloatTensor) -> float32 on the CPU (excitation_bptt.py:36),
+     the same hard-coded-device issue as `.cuda()`.
 
 Parameters come from tests/golden/weights.py (numpy PCG64), loaded into the
 reference modules with load_state_dict, so fixtures hold inputs/outputs only.
@@ -69,6 +74,27 @@ def install_shim(argv):
     sys.modules["datasource"] = ds
     torch.Tensor.cuda = lambda self, *a, **k: self
     nn.Module.cuda = lambda self, *a, **k: self
+    _type = torch.Tensor.type
+
+    def type_on_cpu(self, dtype=None, *a, **k):
+        if dtype is torch.cuda.FloatTensor:
+            dtype = torch.FloatTensor
+        return _type(self, dtype, *a, **k)
+    torch.Tensor.type = type_on_cpu
+    # gym: the numpy games only need gym.spaces.discrete.Discrete(n).n
+    gym = types.ModuleType("gym")
+    spaces = types.ModuleType("gym.spaces")
+    discrete = types.ModuleType("gym.spaces.discrete")
+
+    class Discrete(object):
+        def __init__(self, n):
+            self.n = n
+    discrete.Discrete = Discrete
+    spaces.discrete, spaces.Discrete = discrete, Discrete
+    gym.spaces = spaces
+    sys.modules.update({"gym": gym, "gym.spaces": spaces, "gym.spaces.discrete": discrete})
+    if not hasattr(np, "float"):
+        np.float = float
     sys.argv = argv
     sys.path.insert(0, REF)
 
@@ -469,6 +495,169 @@ def gen_train_flags(out, seed):
     np.savez_compressed(os.path.join(out, "train_flags.npz"), **fx)
 
 
+def gen_planner(out, seed):
+    """The reference's own main.compute_rollout_reward (main.py:455-489), eval mode under no_grad as
+    main.py:95 runs play(): best cumulative reward of the 25- (A=5) and 16-beam (A=4) rollouts, plus
+    every reward-head output along the way (forward hook)."""
+    import main as ref_main
+    import models
+    L, R = 16, 2
+    fx = {}
+    for A, size in ((5, 16), (4, 12)):
+        with circular_pad1():
+            tr = models.Transition(L, A)
+        rp = models.RewardPredictor(L, R)
+        tr.load_state_dict(WS.to_torch(WS.transition_state(seed + 200 + A, actions=A)))
+        rp.load_state_dict(WS.to_torch(WS.reward_state(seed + 210 + A, rewards=R)))
+        ref_main.test_mode([tr, rp])
+        rng = np.random.default_rng(8000 + A)
+        z = torch.from_numpy((rng.random((1, L, size, size)) < 0.5).astype(np.float32))
+        seen = []
+        hook = rp.register_forward_hook(lambda m, i, o: seen.append(npy(o)))
+        with torch.no_grad():
+            best = ref_main.compute_rollout_reward(z, tr, rp, A, 0, rollout_depth=12, rollout_policy='noop')
+        hook.remove()
+        fx["A%d.z" % A] = npy(z)
+        fx["A%d.best" % A] = np.float64(float(best))
+        fx["A%d.rewards" % A] = np.stack(seen)            # (13, A*A, R): reward head after 0..12 transitions
+    np.savez_compressed(os.path.join(out, "planner.npz"), **fx)
+    print("planner.npz:", {k: np.asarray(v).shape for k, v in fx.items()})
+
+
+def gen_bptt(out, seed):
+    """The numeric core of the reference's excitation_bptt.visualize_bptt (excitation_bptt.py:6-53) run as
+    is (video writer stubbed): train-mode transition (straight-through sampler, recorded noise), backward
+    from the arg-max pixel of the reward map once |r| > 0.8; recorded through a wrapper on
+    transition.forward: every a_t, a_t.grad, z_t.grad."""
+    import excitation_bptt as ref_bptt
+    import models
+    L, A, R, size = 16, 4, 2, 16            # visualize_bptt's onehot() is hard-wired to 4 actions
+    with circular_pad1():
+        tr = models.Transition(L, A)
+    rp = models.RewardPredictor(L, R)
+    dec = models.Decoder(L, 3)
+    tr.load_state_dict(WS.to_torch(WS.transition_state(seed + 300, actions=A)))
+    rp.load_state_dict(WS.to_torch(WS.reward_state(seed + 301, rewards=R, gain=0.31)))
+    dec.load_state_dict(WS.to_torch(WS.decoder_state(seed + 302)))
+    tr.train()
+    rng = np.random.default_rng(8100)
+    z0 = torch.from_numpy((rng.random((1, L, size, size)) < 0.5).astype(np.float32)).requires_grad_(True)
+    calls = []
+    orig_forward = tr.forward
+
+    def recording_forward(z, a, *args, **kw):
+        o = orig_forward(z, a, *args, **kw)
+        calls.append((a, o))
+        return o
+    tr.forward = recording_forward
+
+    class Vid(object):
+        frames = 0
+
+        def write_frame(self, *a, **k):
+            Vid.frames += 1
+    rewards_seen = []
+    hook = rp.register_forward_hook(lambda m, i, o: rewards_seen.append(npy(o[0])))
+    with recorded_bernoulli(8200 + seed) as rb:
+        ref_bptt.visualize_bptt(z0, tr, rp, dec, lambda x: x, A, vid=Vid())
+    hook.remove()
+    steps = len(calls)
+    assert 1 < steps < 30, "pick reward-head weights so the 0.8 threshold is crossed after a few steps (got %d)" % steps
+    fx = {"z0": npy(z0), "steps": np.int64(steps), "noise": np.stack(rb.draws),
+          "rewards": np.stack(rewards_seen),                          # (steps, 1, R)
+          "a": np.stack([npy(a) for a, _ in calls]),
+          "a_grad": np.stack([npy(a.grad) for a, _ in calls]),
+          "z_grad": np.stack([npy(o.grad) for _, o in calls]),
+          "z0_grad": npy(z0.grad)}
+    np.savez_compressed(os.path.join(out, "bptt.npz"), **fx)
+    print("bptt.npz: threshold crossed at step %d; |r| per step %s" % (steps - 1, np.abs(fx["rewards"].sum(-1)).ravel()))
+
+
+def gen_envs(out, seed):
+    """Step rules of the reference's pure-numpy games, from the reference modules themselves
+    (envs/gridworld.py, gameoflife.py, betterpong.py behind the gym / np.float stubs): for seeded random
+    (state, action) cases -> next state, reward, done, rendered frame; plus one seeded get_trajectories()
+    call of gridworld (whose state is fully visible in its frames) for the batch conventions."""
+    sys.path.insert(0, os.path.join(REF, "envs"))
+    import gridworld
+    import gameoflife
+    import betterpong
+    rng = np.random.default_rng(9000 + seed)
+    fx = {}
+    # ---- gridworld (envs/gridworld.py:18-57)
+    n = 96
+    env = gridworld.Env()
+    x0, y0 = rng.integers(0, 17, n), rng.integers(2, 15, n)
+    act = rng.integers(0, 4, n)
+    nxt, rew, frames = [], [], []
+    for i in range(n):
+        env.ball_x, env.ball_y = int(x0[i]), int(y0[i])
+        st, r, done, info = env.step(int(act[i]))
+        assert done is False
+        nxt.append((env.ball_x, env.ball_y))
+        rew.append(r)
+        frames.append(st)
+    fx["grid.x"], fx["grid.y"], fx["grid.a"] = x0, y0, act
+    fx["grid.next"] = np.array(nxt, np.int64)
+    fx["grid.reward"] = np.array(rew, np.float64)
+    fx["grid.frames"] = np.packbits(np.array(frames) > 0.5)
+    fx["grid.frames_shape"] = np.array(np.array(frames).shape, np.int64)
+    np.random.seed(77)
+    s, r, d, a = gridworld.get_trajectories(batch_size=6, timesteps=9)
+    fx["grid.traj_states"] = np.packbits(np.asarray(s) > 0.5)
+    fx["grid.traj_states_shape"] = np.array(np.asarray(s).shape, np.int64)
+    fx["grid.traj_rewards"] = np.asarray(r, np.float64)          # (1, T, B): the reference's reward layout quirk
+    fx["grid.traj_dones"] = np.asarray(d)
+    fx["grid.traj_actions"] = np.asarray(a, np.int64)
+    # ---- game of life (envs/gameoflife.py:18-44): 6 boards, 3 consecutive steps each
+    boards, after = [], []
+    for i in range(6):
+        env = gameoflife.Env()
+        env.state = rng.random((64, 64)) > (0.3 + 0.1 * i)
+        boards.append(env.state.copy())
+        seq = []
+        for _ in range(3):
+            st, r, done, info = env.step(0)
+            assert r == 0 and done is False and st.shape == (1, 64, 64)
+            seq.append(st[0] > 0.5)
+        after.append(seq)
+    fx["life.boards"] = np.packbits(np.array(boards))
+    fx["life.after"] = np.packbits(np.array(after))
+    # ---- pong (envs/betterpong.py:24-92): random states incl. positions past the walls and at the paddles
+    n = 512
+    env = betterpong.BetterPongEnv()
+    cols = {k: [] for k in ("left_y", "right_y", "bx", "by", "vx", "vy", "a")}
+    nxt, rew, frames = [], [], []
+    speeds = [-3, -2, 2, 3]
+    for i in range(n):
+        near_paddle = i % 3 == 0
+        c = dict(left_y=int(rng.integers(0, 65)), right_y=int(rng.integers(0, 65)),
+                 bx=int(rng.choice([5, 6, 7, 8, 9, 10, 54, 55, 56, 57, 58, 59])) if near_paddle else int(rng.integers(-4, 69)),
+                 by=int(rng.integers(-2, 67)), vx=int(rng.choice(speeds)), vy=int(rng.choice(speeds)), a=int(rng.integers(0, 4)))
+        if near_paddle and i % 2 == 0:      # make paddle hits likely
+            c["by"] = int(np.clip((c["right_y"] if c["bx"] > 32 else c["left_y"]) + rng.integers(-9, 10), -2, 66))
+        env.left_y, env.right_y, env.ball_x, env.ball_y = c["left_y"], c["right_y"], c["bx"], c["by"]
+        env.ball_velocity_x, env.ball_velocity_y = c["vx"], c["vy"]
+        st, r, done, info = env.step(c["a"])
+        assert done is False
+        for k in cols:
+            cols[k].append(c[k])
+        nxt.append((env.left_y, env.right_y, env.ball_x, env.ball_y, env.ball_velocity_x, env.ball_velocity_y))
+        rew.append(r)
+        if i < 96:
+            frames.append(st)
+    for k, v in cols.items():
+        fx["pong." + k] = np.array(v, np.int64)
+    fx["pong.next"] = np.array(nxt, np.int64)
+    fx["pong.reward"] = np.array(rew, np.float64)
+    fx["pong.frames"] = np.packbits(np.array(frames) > 0.5)
+    fx["pong.frames_shape"] = np.array(np.array(frames).shape, np.int64)
+    np.savez_compressed(os.path.join(out, "envs.npz"), **fx)
+    print("envs.npz: gridworld %d cases (%d scored), life 6x3 boards, pong %d cases (%d scored, %d x-bounces)" % (
+        len(x0), int(np.count_nonzero(fx["grid.reward"])), n, int(np.count_nonzero(fx["pong.reward"])),
+        int(np.sum(np.sign(fx["pong.next"][:, 4]) != np.sign(fx["pong.vx"])))))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=HERE)
@@ -488,6 +677,12 @@ def main():
         gen_train(a.out, a.seed)
     if a.only in ("", "flags"):
         gen_train_flags(a.out, a.seed)
+    if a.only in ("", "planner"):
+        gen_planner(a.out, a.seed)
+    if a.only in ("", "bptt"):
+        gen_bptt(a.out, a.seed)
+    if a.only in ("", "envs"):
+        gen_envs(a.out, a.seed)
 
 
 if __name__ == "__main__":

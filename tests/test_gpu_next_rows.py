@@ -324,3 +324,60 @@ def test_play_agent_on_gridworld_matches_the_eager_planner(tmp_path, monkeypatch
     # agents see slightly different sigma: the first decisions (before that drift matters) must agree
     assert runs[0][2][:3] == runs[1][2][:3], runs
     assert list(tmp_path.glob("evaluation_metrics_*.txt"))
+
+
+def test_compute_rollout_reward_vs_reference_run():
+    """main.compute_rollout_reward and planner.GraphedRollout against the reference's OWN
+    main.compute_rollout_reward run (tests/golden/planner.npz: A=5 at 16x16, A=4 at 12x12): every reward-head
+    output along the 12-step beam (forward hook) and the best cumulative reward."""
+    from scm_gan_amd import main as T, models as M
+    from scm_gan_amd.planner import GraphedRollout
+    fx = load("planner.npz")
+    for A in (5, 4):
+        tr, rp = M.Transition(16, A), M.RewardPredictor(16, 2)
+        tr.load_state_dict(WS.to_torch(WS.transition_state(200 + A, actions=A)))
+        rp.load_state_dict(WS.to_torch(WS.reward_state(210 + A, rewards=2)))
+        T.test_mode([tr, rp])
+        sd = {k: v.clone() for k, v in tr.state_dict().items()}
+        seen = []
+        hook = rp.register_forward_hook(lambda m, i, o: seen.append(o.detach().cpu().numpy().copy()))
+        with torch.no_grad():
+            best = T.compute_rollout_reward(dev(fx["A%d.z" % A]), tr, rp, A, 0, rollout_depth=12, rollout_policy='noop')
+        hook.remove()
+        got = np.stack(seen)
+        ref = fx["A%d.rewards" % A]
+        assert got.shape == ref.shape
+        assert np.abs(got - ref).max() < 1e-4 * max(1.0, np.abs(ref).max()), np.abs(got - ref).max()
+        assert abs(float(best) - float(fx["A%d.best" % A])) < 5e-4 * max(1.0, abs(float(fx["A%d.best" % A])))
+        tr.load_state_dict(sd)                                  # SpectralNorm u / v back to the fixture's start state
+        graphed = GraphedRollout(tr, rp, A)
+        # the graph's warm-up runs advance u / v before the captured replay: equal only up to the power-iteration
+        # drift of sigma (~1e-4 relative after a few calls on these weights)
+        assert abs(float(graphed(dev(fx["A%d.z" % A]))) - float(fx["A%d.best" % A])) < 2e-2 * max(1.0, abs(float(best)))
+
+
+def test_excitation_backtrack_vs_reference_run():
+    """excitation_bptt.excitation_backtrack against the reference's OWN excitation_bptt.visualize_bptt run
+    (tests/golden/bptt.npz): the step the 0.8 threshold is crossed at, rewards, action attributions
+    a_t * dr/da_t and the latent masks |dz_t| / (.001 + max|dz_t|)."""
+    from scm_gan_amd import models as M
+    from scm_gan_amd.excitation_bptt import excitation_backtrack
+    fx = load("bptt.npz")
+    tr, rp = M.Transition(16, 4), M.RewardPredictor(16, 2)
+    tr.load_state_dict(WS.to_torch(WS.transition_state(300, actions=4)))
+    rp.load_state_dict(WS.to_torch(WS.reward_state(301, rewards=2, gain=0.31)))
+    tr.train()
+    tr.set_noise([dev(n) for n in fx["noise"]])
+    out = excitation_backtrack(dev(fx["z0"]), tr, rp, 4, steps=30, threshold=0.8)
+    steps = int(fx["steps"])
+    assert out is not None and out["t"] == steps - 1
+    assert np.abs(out["reward"].cpu().numpy() - fx["rewards"][-1]).max() < 1e-4
+    for t in range(steps):
+        want = fx["a"][t] * fx["a_grad"][t]
+        got = out["action_attributions"][t].cpu().numpy()
+        assert np.abs(got - want).max() < 1e-6 + 2e-3 * np.abs(fx["a_grad"]).max(), (t, got, want)
+    for i, t in enumerate(range(steps - 1, -1, -1)):            # latest step first
+        g = np.abs(fx["z_grad"][t])
+        want = g / (.001 + g.max())
+        got = out["latent_masks"][i].cpu().numpy()
+        assert np.abs(got - want).max() < 2e-3, (t, np.abs(got - want).max())

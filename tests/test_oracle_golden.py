@@ -199,3 +199,34 @@ def test_train_and_rollout():
     assert np.allclose(out["mse_std"], fx["eval_std_pixel"], atol=1e-6)
     assert np.allclose(out["rew"], fx["eval_mse_reward"], rtol=1e-4, atol=1e-5)
     assert np.allclose(out["rew_std"], fx["eval_std_reward"], rtol=1e-4, atol=1e-5)
+
+
+def test_planner_rollout_vs_reference_run():
+    """oracle.compute_rollout_reward vs the reference's own main.compute_rollout_reward run
+    (tests/golden/planner.npz): every reward-head output along the 12-step beam and the best value."""
+    fx = load("planner.npz")
+    for A in (5, 4):
+        tr = O.clone_state(WS.transition_state(200 + A, actions=A))
+        rp = O.clone_state(WS.reward_state(210 + A, rewards=2))
+        best, cum = O.compute_rollout_reward(torch.from_numpy(fx["A%d.z" % A]), tr, rp, A)
+        want = fx["A%d.rewards" % A].sum(0)
+        want[:, 0] *= 10.0                                              # main.py:484
+        assert np.allclose(cum.numpy(), want, atol=2e-5, rtol=1e-5), np.abs(cum.numpy() - want).max()
+        assert abs(float(best) - float(fx["A%d.best" % A])) < 2e-5
+
+
+def test_excitation_backtrack_vs_reference_run():
+    """oracle.excitation_backtrack vs the reference's own excitation_bptt.visualize_bptt run
+    (tests/golden/bptt.npz): threshold step, rewards, d/da_t and d/dz_t of the arg-max reward pixel."""
+    fx = load("bptt.npz")
+    tr = O.clone_state(WS.transition_state(300, actions=4))
+    rp = O.clone_state(WS.reward_state(301, rewards=2, gain=0.31))
+    out = O.excitation_backtrack(tr, rp, torch.from_numpy(fx["z0"]), 4, [torch.from_numpy(n) for n in fx["noise"]])
+    steps = int(fx["steps"])
+    assert out is not None and out["t"] == steps - 1
+    assert np.allclose(torch.stack(out["rewards"]).numpy(), fx["rewards"], atol=1e-5)
+    for t in range(steps):
+        assert np.array_equal(out["a"][t].numpy(), fx["a"][t])
+        assert np.allclose(out["a_grad"][t].numpy(), fx["a_grad"][t], atol=1e-6, rtol=1e-3), t
+        assert np.allclose(out["z_grad"][t].numpy(), fx["z_grad"][t], atol=1e-7, rtol=1e-3), t
+    assert np.allclose(out["z0_grad"].numpy(), fx["z0_grad"], atol=1e-7, rtol=1e-3)
