@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <atomic>
 #include "../../include/scm_hip.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -12,6 +13,22 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // thread-local error slot, defined in api.cpp
 void scm_set_error(const char* fmt, ...);
 int scm_check_hip(hipError_t e, const char* what);
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device function attribute: set it once per
+// (kernel, device), from any host thread.  `done` is one bit per device ordinal of the calling
+// thread's current device (a static std::atomic<uint64_t> next to each kernel instantiation).
+static inline int scm_ensure_lds_attr(const void* kernel, std::atomic<uint64_t>& done, int bytes) {
+    int dev = 0;
+    int rc = scm_check_hip(hipGetDevice(&dev), "hipGetDevice");
+    if (rc) return rc;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return 0;
+    rc = scm_check_hip(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes),
+                       "hipFuncSetAttribute");
+    if (rc) return rc;
+    done.fetch_or(bit, std::memory_order_release);
+    return 0;
+}
 
 #define SCM_REQUIRE(cond, ...)                 \
     do {                                       \

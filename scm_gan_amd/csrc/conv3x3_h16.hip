@@ -413,14 +413,8 @@ static int launch_h16_nj(const ConvKArgs& a, int groups, hipStream_t s) {
     constexpr size_t lds = (lds_main > ep_bytes ? lds_main : ep_bytes) + CT * 32 * sizeof(float);   // + bias table
     static_assert(lds <= 160 * 1024, "halo tile exceeds the LDS");
     auto kern = conv3x3_h16_kernel<PREC, CT, 4, NJ, GATED>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        int rc = scm_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
-                               "hipFuncSetAttribute");
-        if (rc) return rc;
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};       // per (instantiation, device)
+    if (int rc = scm_ensure_lds_attr(reinterpret_cast<const void*>(kern), attr_done, 160 * 1024)) return rc;
     hipLaunchKernelGGL(kern, dim3(a.B * a.tiles_per_img, groups), dim3(256), lds, s, a);
     SCM_LAUNCH_CHECK("conv3x3_h16_kernel");
     return SCM_OK;

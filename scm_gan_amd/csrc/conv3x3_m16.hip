@@ -200,14 +200,8 @@ static int launch_m16(const ConvKArgs& a, hipStream_t s) {
     constexpr int WR = (KC * 9 * 16 + 255) / 256;
     const size_t lds = ((size_t)WR * 256 + (size_t)KC * (NJ * 256 + 16)) * sizeof(float);
     auto kern = conv3x3_m16_kernel<NJ, GATED>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        int rc = scm_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
-                               "hipFuncSetAttribute");
-        if (rc) return rc;
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};       // per (instantiation, device)
+    if (int rc = scm_ensure_lds_attr(reinterpret_cast<const void*>(kern), attr_done, 160 * 1024)) return rc;
     hipLaunchKernelGGL(kern, dim3(a.B * a.tiles_per_img), dim3(256), lds, s, a);
     SCM_LAUNCH_CHECK("conv3x3_m16_kernel");
     return SCM_OK;

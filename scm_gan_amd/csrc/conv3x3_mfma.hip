@@ -436,14 +436,8 @@ static int launch_conv_nj(const ConvKArgs& a, int groups, hipStream_t s) {
     const size_t lds = ((size_t)WR * 256 * 4 + (size_t)KC * NJ * 256) * sizeof(float) * ((NJ == 4 && WPS == 1) ? 2 : 1) +
                        CT * 32 * sizeof(float);       // + bias table
     auto kern = conv3x3_mfma_kernel<CT, PT, NJ, GATED, WPS>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        int rc = scm_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
-                               "hipFuncSetAttribute");
-        if (rc) return rc;
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};       // per (instantiation, device)
+    if (int rc = scm_ensure_lds_attr(reinterpret_cast<const void*>(kern), attr_done, 160 * 1024)) return rc;
     if (lds > 160 * 1024) {
         scm_set_error("scm_conv3x3: halo tile of %zu bytes exceeds the LDS", lds);
         return SCM_EUNSUPPORTED;

@@ -586,13 +586,14 @@ static int launch_wgrad_m(const WgradKArgs& a, const WgradPlan& p, hipStream_t s
     const int PSP = a.PS + 4, XPL = (4 * PSP) | 1, DPL = (a.PS + 2) | 1;
     const size_t lds = ((size_t)NT * 32 * XPL + (size_t)2 * MT * 32 * DPL) * sizeof(float);
     auto kern = conv3x3_wgrad_kernel<WM, WN, NTW, MASK>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        int rc = scm_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
-                               "hipFuncSetAttribute");
-        if (rc) return rc;
-        attr_set = true;
+    static std::atomic<uint64_t> attr_done{0};       // per (instantiation, device)
+    if (int rc = scm_ensure_lds_attr(reinterpret_cast<const void*>(kern), attr_done, 160 * 1024)) return rc;
+    if (lds > 160 * 1024) {
+        // e.g. 33..64 output channels from > 64 input channels on 64-wide maps (174 080 B): no shipped layer has
+        // that shape; fail with a message instead of an opaque launch error (the forward conv checks the same way)
+        scm_set_error("scm_conv3x3_wgrad: the <%d,%d> tile needs %zu bytes of LDS at row segment %d (limit 160 KB)", WM,
+                      NT, lds, a.PS);
+        return SCM_EUNSUPPORTED;
     }
     dim3 grid(p.nsplit, p.co_groups * p.ci_groups);
     hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, s, a);
@@ -643,14 +644,13 @@ static int wgrad_impl(const scm_conv3x3_wgrad_desc* d, int precision, void* stre
         const bool mk = p.m16 == 2 && a.gate_mask != nullptr && a.gate_act == SCM_ACT_LRELU;
         auto kern = p.m16 == 1 ? conv3x3_wgrad_m16_kernel<1, 8, false>
                                : (mk ? conv3x3_wgrad_m16_kernel<8, 1, true> : conv3x3_wgrad_m16_kernel<8, 1, false>);
-        static bool attr_set[3] = {false, false, false};
+        static std::atomic<uint64_t> attr_done[3];        // per (instantiation, device)
         const int ai = p.m16 == 1 ? 0 : (mk ? 2 : 1);
-        if (!attr_set[ai]) {
-            rc = scm_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
-                               "hipFuncSetAttribute");
-            if (rc) return rc;
-            attr_set[ai] = true;
+        if ((rc = scm_ensure_lds_attr(reinterpret_cast<const void*>(kern), attr_done[ai], 160 * 1024))) return rc;
+        if (lds > 160 * 1024) {
+            scm_set_error("scm_conv3x3_wgrad: %zu bytes of LDS needed for %d -> %d channels at width %d (limit 160 KB)",
+                          lds, cin, d->cout, d->W);
+            return SCM_EUNSUPPORTED;
         }
         hipLaunchKernelGGL(kern, dim3(p.nsplit, p.co_groups * p.ci_groups), dim3(512), lds, s, a);
         SCM_LAUNCH_CHECK("conv3x3_wgrad_m16_kernel");

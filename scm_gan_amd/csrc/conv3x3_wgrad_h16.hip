@@ -286,14 +286,8 @@ template <int PREC, bool VEC, int WN>
 static int launch_wgrad_h16(const WgradKArgs& a, const WgradPlan& p, hipStream_t s) {
     const size_t lds = ((size_t)4 * 3 * WG_NG * (WN * 32 + 1) + 2 * WG_DSTAGE) * 16;
     auto kern = conv3x3_wgrad_h16_kernel<PREC, VEC, WN>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        int rc = scm_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
-                               "hipFuncSetAttribute");
-        if (rc) return rc;
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};       // per (instantiation, device)
+    if (int rc = scm_ensure_lds_attr(reinterpret_cast<const void*>(kern), attr_done, 160 * 1024)) return rc;
     hipLaunchKernelGGL(kern, dim3(p.nsplit, p.co_groups * p.ci_groups), dim3(256 * WN), lds, s, a);
     SCM_LAUNCH_CHECK("conv3x3_wgrad_h16_kernel");
     return SCM_OK;
