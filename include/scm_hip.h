@@ -311,6 +311,60 @@ int scm_csrn_sweep_fwd(const scm_csrn_desc* d, void* stream);
 int scm_csrn_sweep_bwd(const scm_csrn_desc* d, const float* dctx, float* dx, float* slab, float* dparams,
                        void* stream);
 
+/* ------------------------------------------------------------------------
+ * Fused decoder + pixel loss: one pass over the latent (SURVEY.md 8(b) scm_decoder_fused_*).
+ *
+ * Replaces Decoder.forward (models.py:270-291: ConvTranspose2d 16->64 + leaky_relu, ConvTranspose2d
+ * 64->16*C, view(B,16,C,H,W).sum(dim=1)), the torch.sigmoid + decoder_pixel_loss of the training loop
+ * (main.py:188-190, 310-312) or the squared error of the eval rollout (main.py:814-816), and their autograd
+ * backward (main.py:285).  The 64-channel hidden map and the 16*C-channel per-factor map never exist in
+ * HBM: per frame the forward reads 16 latent planes and writes C logit planes.  latent_size 16, C <= 3.
+ *
+ *   pack   : scm_decoder_fused_pack_floats() floats, built by scm_decoder_fused_pack from the four
+ *            ConvTranspose2d parameters: conv1.weight (16,64,3,3), conv1.bias (64), conv2.weight (64,16*C,3,3),
+ *            conv2.bias (16*C); rebuild whenever they change.
+ *   fwd    : logits[B][C][H][W] (optional, may be NULL when only the loss is wanted);
+ *            loss_kind 0: loss[b] = mean_{c,h,w} BCE(sigmoid(logit), target) with torch's log clamp at -100,
+ *            loss_kind 1: mean squared error of sigmoid(logit), loss_kind -1: no loss (target/loss may be NULL).
+ *            workspace: scm_decoder_fused_workspace()'s fwd_floats (per-workgroup loss partials, summed in a
+ *            fixed order: bitwise reproducible).
+ * ---------------------------------------------------------------------- */
+typedef struct scm_decoder_fused_desc {
+    const float* z;          /* [B][16][H][W] */
+    const float* pack;
+    const float* target;     /* [B][C][H][W] or NULL */
+    float* logits;           /* [B][C][H][W] or NULL */
+    float* loss;             /* [B] or NULL */
+    float* workspace;
+    int32_t B; int32_t H; int32_t W; int32_t C;
+    int32_t loss_kind;
+} scm_decoder_fused_desc;
+
+size_t scm_decoder_fused_pack_floats(void);
+int scm_decoder_fused_pack(const float* conv1_weight, const float* conv1_bias, const float* conv2_weight,
+                           const float* conv2_bias, int latent, int C, float* pack, void* stream);
+int scm_decoder_fused_workspace(int B, int H, int W, int C, size_t* fwd_floats, size_t* bwd_floats);
+int scm_decoder_fused_fwd(const scm_decoder_fused_desc* d, void* stream);
+
+/* Backward of the fused decoder + loss (autograd of models.py:270-291 + main.py:188-190 under main.py:285).
+ * h is recomputed from z; dl = g_loss[b]/n * dloss/dlogit comes from the saved logits and the target.
+ *   dz                    [B][16][H][W], written
+ *   d_conv{1,2}_{weight,bias}: gradients in the ConvTranspose2d parameter layouts (conv2's broadcast over the 16
+ *                         factors); accumulate != 0 adds into them (existing .grad buffers), else overwrites
+ *   workspace             scm_decoder_fused_workspace()'s bwd_floats (per-workgroup partial slabs, fixed-order sum) */
+typedef struct scm_decoder_fused_bwd_desc {
+    const float* z; const float* pack; const float* logits; const float* target;
+    const float* g_loss;     /* [B] upstream gradient of the per-sample loss */
+    float* dz;
+    float* d_conv1_weight; float* d_conv1_bias; float* d_conv2_weight; float* d_conv2_bias;
+    float* workspace;
+    int32_t B; int32_t H; int32_t W; int32_t C;
+    int32_t loss_kind;       /* 0 BCE, 1 squared error */
+    int32_t accumulate;
+} scm_decoder_fused_bwd_desc;
+
+int scm_decoder_fused_bwd(const scm_decoder_fused_bwd_desc* d, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -64,6 +64,24 @@ class Conv2dDesc(ctypes.Structure):
                 ("act", ctypes.c_int32)]
 
 
+class DecoderFusedDesc(ctypes.Structure):
+    """Mirror of scm_decoder_fused_desc."""
+    _fields_ = [("z", ctypes.c_void_p), ("pack", ctypes.c_void_p), ("target", ctypes.c_void_p),
+                ("logits", ctypes.c_void_p), ("loss", ctypes.c_void_p), ("workspace", ctypes.c_void_p),
+                ("B", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32), ("C", ctypes.c_int32),
+                ("loss_kind", ctypes.c_int32)]
+
+
+class DecoderFusedBwdDesc(ctypes.Structure):
+    """Mirror of scm_decoder_fused_bwd_desc."""
+    _fields_ = [("z", ctypes.c_void_p), ("pack", ctypes.c_void_p), ("logits", ctypes.c_void_p), ("target", ctypes.c_void_p),
+                ("g_loss", ctypes.c_void_p), ("dz", ctypes.c_void_p),
+                ("d_conv1_weight", ctypes.c_void_p), ("d_conv1_bias", ctypes.c_void_p),
+                ("d_conv2_weight", ctypes.c_void_p), ("d_conv2_bias", ctypes.c_void_p), ("workspace", ctypes.c_void_p),
+                ("B", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32), ("C", ctypes.c_int32),
+                ("loss_kind", ctypes.c_int32), ("accumulate", ctypes.c_int32)]
+
+
 class CsrnDesc(ctypes.Structure):
     """Mirror of scm_csrn_desc."""
     _fields_ = [("x", ctypes.c_void_p), ("ctx", ctypes.c_void_p), ("hprev", ctypes.c_void_p),
@@ -126,12 +144,17 @@ def lib():
             "scm_csrn_sweep_fwd": [vp, vp],
             "scm_csrn_sweep_bwd": [vp, vp, vp, vp, vp, vp],
             "scm_adam_clip_multi": [ci, vp, vp, vp, vp, vp, cf, cf, cf, cf, ci, cf, cf, vp],
+            "scm_decoder_fused_pack_floats": [],
+            "scm_decoder_fused_pack": [vp, vp, vp, vp, ci, ci, vp, vp],
+            "scm_decoder_fused_workspace": [ci, ci, ci, ci, vp, vp],
+            "scm_decoder_fused_fwd": [vp, vp],
+            "scm_decoder_fused_bwd": [vp, vp],
         }
         for name, args in sigs.items():
             fn = getattr(L, name)      # raises AttributeError when the library lacks a declared symbol
             fn.argtypes = args
             fn.restype = ctypes.c_size_t if name in ("scm_conv3x3_pack_floats", "scm_conv2d_bwd_workspace",
-                                                  "scm_conv3x3_pack_h16_bytes") \
+                                                  "scm_conv3x3_pack_h16_bytes", "scm_decoder_fused_pack_floats") \
                 else ctypes.c_int
         L._scm_symbols = sorted(sigs) + ["scm_version", "scm_last_error"]
         _lib = L

@@ -133,6 +133,16 @@ _FlatGrads = dp.FlatGrads        # (kept under the round-1 names: tests import t
 _dist = dp.world_info
 
 
+def decoder_frame_loss(decoder, z, target, kind=0):
+    """Per-sample loss of the decoded frame: main.py:188-190 (kind 0: sigmoid + decoder_pixel_loss) or the squared
+    error of main.py:814-816 (kind 1).  A decoder with forward_loss (scm_gan_amd.models.Decoder) computes it in one
+    fused pass over z; any other module goes through its forward."""
+    if hasattr(decoder, 'forward_loss'):
+        return decoder.forward_loss(z, target, kind)
+    logits = decoder(z)
+    return decoder_pixel_loss(target, logits) if kind == 0 else ops.pixel_mse(logits, target)
+
+
 class Trainer(object):
     """One training iteration of main.py:143-297 on device-resident batches.
 
@@ -214,7 +224,7 @@ class Trainer(object):
         lo_z_set = {}
         for t in range(1, prediction_horizon - 1):                             # main.py:177
             expected_reward = reward_predictor(z)                              # main.py:181
-            rec_loss_batch = decoder_pixel_loss(targets[t], decoder(z))        # main.py:188-190
+            rec_loss_batch = decoder_frame_loss(decoder, z, targets[t])        # main.py:188-190
             if a.truncate_bptt and t > 1:
                 z = z.detach()
             # main.py:178,182-185,195-197 in one launch: mask update, both masked means, loss accumulation
@@ -503,7 +513,7 @@ def measure_prediction_mse(datasource, encoder, decoder, transition, reward_pred
         if float(active_mask.sum()) == 0:
             say('Ending simulation at max trajectory length {}'.format(t))
             break
-        diffs = active_mask * ops.pixel_mse(decoder(z), states[:, t])
+        diffs = active_mask * decoder_frame_loss(decoder, z, states[:, t].contiguous(), kind=1)
         scale = batch_size / torch.sum(active_mask)
         mse_losses.append(float(torch.mean(diffs) * scale))
         mse_stddevs.append(float(torch.std(diffs) * scale))

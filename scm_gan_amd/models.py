@@ -10,6 +10,8 @@ Differences from the reference, all deliberate and documented in DESIGN.md:
     SURVEY.md section 0.4);
   * modules move to the GPU in their constructor only when one is visible.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -159,8 +161,35 @@ class Decoder(nn.Module):
         self.conv2 = ConvTranspose3x3(latent_size * 4, latent_size * self.color_channels)
         _to_gpu(self)
 
+    # ---- fused path (scm_decoder_fused_*): one pass over z, the 64-channel hidden map stays on chip.
+    # Serves latent_size 16 and <= 3 colour channels in the fp32 mode; anything else takes the layer-by-layer path.
+    def _fused(self):
+        return self.latent_size == 16 and self.color_channels <= 3 and ops.compute_precision() == "fp32" \
+            and os.environ.get("SCM_NO_FUSED_DECODER", "0") in ("", "0")
+
+    def _fused_pack(self):
+        ps = (self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias)
+        key = (ops.weights_epoch(),) + tuple((p.data_ptr(), p._version) for p in ps)
+        if getattr(self, "_fpack_key", None) != key:
+            self._fpack = ops.decoder_fused_pack(*ps, self.latent_size, self.color_channels)
+            self._fpack_key = key
+        return self._fpack
+
+    def forward_loss(self, z_map, target, kind=0):
+        """Per-sample pixel loss of the decoded frame against `target` (B, C, H, W) without materialising anything
+        but the logits: kind 0 = mean BCE of sigmoid(decoder(z)) (main.py:188-190 + decoder_pixel_loss, :310-312),
+        kind 1 = mean squared error (main.py:814-816).  Differentiable w.r.t. z and the decoder's parameters."""
+        if not self._fused():
+            return ops.PixelLossFn.apply(self.forward(z_map), target, kind)
+        loss, _ = ops.DecoderLossFn.apply(z_map, target, self.conv1.weight, self.conv1.bias, self.conv2.weight,
+                                          self.conv2.bias, self._fused_pack(), kind)
+        return loss
+
     def forward(self, z_map, visualize=False):
         batch_size, latent_size, height, width = z_map.shape
+        if not visualize and not torch.is_grad_enabled() and self._fused():
+            # inference (eval rollout, planner frames): the fused forward, logits only
+            return ops.decoder_fused_fwd(z_map, self._fused_pack(), self.color_channels)[0]
         x = self.conv1(z_map, act=ops.ACT_LRELU)
         if visualize:
             # the per-factor maps are wanted: materialise conv2's latent_size*C channels (models.py:278-290)

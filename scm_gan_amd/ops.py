@@ -502,6 +502,84 @@ class LinearFn(Function):
         return dx, dw, (db if ctx.has_bias else None), None
 
 
+# ---------------------------------------------------------- fused decoder
+def decoder_fused_pack(w1, b1, w2, b2, latent, C):
+    """Weight packs of the fused decoder kernels from the four ConvTranspose2d parameters."""
+    lib = L.lib()
+    ts = [_chk(t.detach(), "decoder_fused_pack") for t in (w1, b1, w2, b2)]
+    pack = _new(ts[0], lib.scm_decoder_fused_pack_floats())
+    L.check(lib.scm_decoder_fused_pack(_p(ts[0]), _p(ts[1]), _p(ts[2]), _p(ts[3]), latent, C, _p(pack), _stream()),
+            "scm_decoder_fused_pack")
+    return pack
+
+
+def _decoder_fused_ws(B, H, W, C):
+    f, b = ctypes.c_size_t(), ctypes.c_size_t()
+    L.check(L.lib().scm_decoder_fused_workspace(B, H, W, C, ctypes.byref(f), ctypes.byref(b)), "scm_decoder_fused_workspace")
+    return f.value, b.value
+
+
+def decoder_fused_fwd(z, pack, C, target=None, loss_kind=-1, want_logits=True):
+    """(logits or None, per-sample loss or None) of the fused decoder forward (no autograd)."""
+    z = _chk(z, "decoder_fused")
+    target = _chk(target, "decoder_fused")
+    B, _, H, W = z.shape
+    logits = _new(z, B, C, H, W) if want_logits else None
+    loss = _new(z, B) if loss_kind >= 0 else None
+    ws = _new(z, max(1, _decoder_fused_ws(B, H, W, C)[0])) if loss_kind >= 0 else None
+    d = L.DecoderFusedDesc(_p(z), _p(pack), _p(target), _p(logits), _p(loss), _p(ws), B, H, W, C, loss_kind)
+    if kernel_timer is not None:
+        ev = kernel_timer.bracket("decoder_fused_fwd", 2.0 * B * H * W * 9 * (16 * 64 + 64 * C))
+        ev[0].record()
+    L.check(L.lib().scm_decoder_fused_fwd(ctypes.byref(d), _stream()), "scm_decoder_fused_fwd")
+    if kernel_timer is not None:
+        ev[1].record()
+    return logits, loss
+
+
+class DecoderLossFn(Function):
+    """Per-sample pixel loss of the decoded frame in one pass over z (scm_decoder_fused_fwd / _bwd):
+    loss[b] = mean_{c,h,w} loss(sigmoid(Decoder(z)), target), kind 0 = BCE (main.py:188-190, 310-312), kind 1 =
+    squared error (main.py:814-816).  The 64-channel hidden map exists only inside the kernels; backward
+    recomputes it from z.  Returns (loss, logits); logits carry no gradient."""
+
+    @staticmethod
+    def forward(ctx, z, target, w1, b1, w2, b2, pack, kind):
+        z = _chk(z, "decoder_loss")
+        target = _chk(target, "decoder_loss")
+        C = target.shape[1]
+        logits, loss = decoder_fused_fwd(z, pack, C, target, kind, True)
+        ctx.kind, ctx.C = kind, C
+        ctx.params = (w1, b1, w2, b2)
+        ctx.save_for_backward(z, target, logits, pack)
+        ctx.mark_non_differentiable(logits)
+        return loss, logits
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_logits):
+        z, target, logits, pack = ctx.saved_tensors
+        g_loss = _chk(g_loss, "decoder_loss.backward")
+        B, _, H, W = z.shape
+        C = ctx.C
+        w1, b1, w2, b2 = ctx.params
+        sinks = [_grad_sink(p) for p in ctx.params]
+        acc = all(s is not None for s in sinks)
+        grads = sinks if acc else [torch.empty_like(p) for p in ctx.params]
+        dz = torch.empty_like(z)
+        ws = _new(z, max(1, _decoder_fused_ws(B, H, W, C)[1]))
+        d = L.DecoderFusedBwdDesc(_p(z), _p(pack), _p(logits), _p(target), _p(g_loss), _p(dz), _p(grads[0]), _p(grads[1]),
+                                  _p(grads[2]), _p(grads[3]), _p(ws), B, H, W, C, ctx.kind, 1 if acc else 0)
+        if kernel_timer is not None:
+            ev = kernel_timer.bracket("decoder_fused_bwd", 2.0 * B * H * W * 9 * (4 * 16 * 64 + 2 * 64 * C))
+            ev[0].record()
+        L.check(L.lib().scm_decoder_fused_bwd(ctypes.byref(d), _stream()), "scm_decoder_fused_bwd")
+        if kernel_timer is not None:
+            ev[1].record()
+        if acc:
+            return dz, None, None, None, None, None, None, None
+        return dz, None, grads[0], grads[1], grads[2], grads[3], None, None
+
+
 _mean_weights = {}
 
 
