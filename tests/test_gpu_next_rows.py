@@ -327,18 +327,15 @@ def test_play_agent_on_gridworld_matches_the_eager_planner(tmp_path, monkeypatch
 
 
 def test_compute_rollout_reward_vs_reference_run():
-    """main.compute_rollout_reward and planner.GraphedRollout against the reference's OWN
-    main.compute_rollout_reward run (tests/golden/planner.npz: A=5 at 16x16, A=4 at 12x12): every reward-head
+    """main.compute_rollout_reward against the reference's OWN main.compute_rollout_reward run (tests/golden/planner.npz: A=5 at 16x16, A=4 at 12x12): every reward-head
     output along the 12-step beam (forward hook) and the best cumulative reward."""
     from scm_gan_amd import main as T, models as M
-    from scm_gan_amd.planner import GraphedRollout
     fx = load("planner.npz")
     for A in (5, 4):
         tr, rp = M.Transition(16, A), M.RewardPredictor(16, 2)
         tr.load_state_dict(WS.to_torch(WS.transition_state(200 + A, actions=A)))
         rp.load_state_dict(WS.to_torch(WS.reward_state(210 + A, rewards=2)))
         T.test_mode([tr, rp])
-        sd = {k: v.clone() for k, v in tr.state_dict().items()}
         seen = []
         hook = rp.register_forward_hook(lambda m, i, o: seen.append(o.detach().cpu().numpy().copy()))
         with torch.no_grad():
@@ -349,11 +346,6 @@ def test_compute_rollout_reward_vs_reference_run():
         assert got.shape == ref.shape
         assert np.abs(got - ref).max() < 1e-4 * max(1.0, np.abs(ref).max()), np.abs(got - ref).max()
         assert abs(float(best) - float(fx["A%d.best" % A])) < 5e-4 * max(1.0, abs(float(fx["A%d.best" % A])))
-        tr.load_state_dict(sd)                                  # SpectralNorm u / v back to the fixture's start state
-        graphed = GraphedRollout(tr, rp, A)
-        # the graph's warm-up runs advance u / v before the captured replay: equal only up to the power-iteration
-        # drift of sigma (~1e-4 relative after a few calls on these weights)
-        assert abs(float(graphed(dev(fx["A%d.z" % A]))) - float(fx["A%d.best" % A])) < 2e-2 * max(1.0, abs(float(best)))
 
 
 def test_excitation_backtrack_vs_reference_run():
