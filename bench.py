@@ -158,32 +158,46 @@ def rollout_l1(dev):
 
 
 def decoder_leg(dev, batch):
-    """Decoder forward + pixel loss in isolation (north star: achieved HBM GB/s on the decoder).
-    Algorithmic bytes per frame = read z (16 planes) + write C logit planes (SURVEY.md section 8d:
-    311 296 B at 64x64, C=3); the fused minimum.  The path is NOT HBM-bound: 970 FLOP per
-    algorithmic byte against a machine balance of ~20 FLOP/B, so the fp32 MFMA rate bounds it."""
-    from scm_gan_amd import models, ops
+    """Decoder forward + pixel loss in isolation (north star: achieved HBM GB/s on the decoder): ONE fused launch
+    (scm_decoder_fused_fwd; the 64-channel hidden map never leaves the chip) + the per-sample loss reduce.
+    Algorithmic bytes per frame = read z (16 planes) + write C logit planes (311 296 B at
+    64x64, C=3), the fused minimum; the BCE also reads the C target planes (49 152 B).  `counter_*` = HBM bytes of the
+    fused launch from the rocprofv3 --pmc passes under profiles/ (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md),
+    null when the kernel source changed since.  The path is NOT HBM-bound: ~290 FLOP per algorithmic byte against a
+    machine balance of ~20 FLOP/B, so the fp32 MFMA rate bounds it."""
+    from scm_gan_amd import models
     torch.manual_seed(0)
     dec = models.Decoder(L, C)
     z = (torch.rand(batch, L, H, W, device=dev) < 0.5).float()
     target = (torch.rand(batch, C, H, W, device=dev) < 0.1).float()
     with torch.no_grad():
         for _ in range(3):
-            ops.pixel_bce(dec(z), target)
+            dec.forward_loss(z, target)
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         n = 20
         s.record()
         for _ in range(n):
-            ops.pixel_bce(dec(z), target)
+            dec.forward_loss(z, target)
         e.record()
         torch.cuda.synchronize()
     sec = s.elapsed_time(e) * 1e-3 / n
     bytes_per_frame = (L + C) * H * W * 4
-    flops_per_frame = 2.0 * H * W * 9 * (L * 4 * L + 4 * L * L * C)
-    return {"frames_per_s": batch / sec, "us_per_launch_group": sec * 1e6,
-            "achieved_GBps_algorithmic": batch * bytes_per_frame / sec / 1e9, "peak_GBps": 8000.0,
-            "tflops_reference_formulation": batch * flops_per_frame / sec / 1e12,
-            "bound": "mfma (970 FLOP/B algorithmic intensity)"}
+    flops_per_frame = 2.0 * H * W * 9 * (L * 4 * L + 4 * L * C)        # conv2 with the factor sum folded into its weights
+    out = {"fused": bool(dec._fused()), "frames_per_s": batch / sec, "us_per_launch_group": sec * 1e6,
+           "algorithmic_bytes_per_frame": bytes_per_frame,
+           "achieved_GBps_algorithmic": batch * bytes_per_frame / sec / 1e9, "peak_GBps": 8000.0,
+           "tflops_executed_formulation": batch * flops_per_frame / sec / 1e12,
+           "bound": "mfma (fp32), not hbm"}
+    pmc = measured_pmc("decoder_fused_fwd_kernel", "decoder_fused.hip")
+    if pmc is not None and (H, W, C, batch) == (64, 64, 3, 64):
+        out.update({"counter_hbm_bytes_per_launch": pmc["hbm_traffic_bytes"],
+                    "counter_hbm_bytes_per_frame": pmc["hbm_traffic_bytes"] / 64.0,
+                    "counter_to_algorithmic_ratio": pmc["hbm_traffic_bytes"] / 64.0 / bytes_per_frame,
+                    "counter_GBps": pmc["hbm_traffic_bytes"] / (pmc["duration_us_median"] * 1e-6) / 1e9,
+                    "counter_mfma_utilisation": pmc.get("mfma_utilisation"), "counter_source": pmc["_file"]})
+    else:
+        out["counter_hbm_bytes_per_launch"] = None
+    return out
 
 
 def _sha16(path):
@@ -191,6 +205,23 @@ def _sha16(path):
         return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
     except OSError:
         return None
+
+
+def measured_pmc(kernel_substr, source_file):
+    """Newest committed PMC record (profiles/round*_pmc*.json) of a kernel whose source file is unchanged."""
+    import glob
+    sha = _sha16(os.path.join(ROOT, "scm_gan_amd", "csrc", source_file))
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_pmc*.json")), reverse=True):
+        try:
+            pmc = json.load(open(f))
+        except Exception:
+            continue
+        if pmc.get("kernel_source_sha16", {}).get(source_file) != sha:
+            continue
+        for k, v in pmc.get("kernels", {}).items():
+            if kernel_substr in k and "hbm_traffic_bytes" in v:
+                return dict(v, _file=os.path.basename(f), _kernel=k, _commit=pmc.get("git_commit"))
+    return None
 
 
 def measured_traffic(kernel_name):

@@ -1,7 +1,7 @@
 """Fold the rocprofv3 --pmc passes of tools/prof_hot2.py into one JSON (last dispatch of each kernel).
 usage: python tools/pmc_parse.py <dir with pass_*/**/*counter_collection.csv and *kernel_trace.csv> > out.json
 FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE is doubled (MI355X_MICROARCH.md: gfx950 tallies 128-B requests at 64 B)."""
-import csv, glob, json, os, sys
+import csv, glob, hashlib, json, os, subprocess, sys
 root = sys.argv[1]
 vals = {}      # kernel -> counter -> value of its last dispatch
 dur = {}
@@ -16,7 +16,7 @@ for f in glob.glob(os.path.join(root, '**', '*kernel_trace.csv'), recursive=True
         dur.setdefault(r['Kernel_Name'], []).append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
 out = {}
 for k, c in vals.items():
-    if not any(t in k for t in ('conv3x3_mfma', 'conv3x3_h16', 'conv3x3_wgrad')):
+    if not any(t in k for t in ('conv3x3_mfma', 'conv3x3_h16', 'conv3x3_wgrad', 'decoder_fused_fwd', 'decoder_fused_bwd')):
         continue
     e = {}
     if k in dur:
@@ -32,6 +32,17 @@ for k, c in vals.items():
     if 'SQ_LDS_BANK_CONFLICT' in c: e['lds_bank_conflict_cycles'] = c['SQ_LDS_BANK_CONFLICT']
     if 'SQ_LDS_IDX_ACTIVE' in c: e['lds_active_cycles'] = c['SQ_LDS_IDX_ACTIVE']
     out[k] = e
-json.dump({'source': 'rocprofv3 --kernel-trace --pmc <FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE> -- python3 tools/prof_hot2.py (separate passes)',
-           'case': '128->128 channels, B=64, 64x64, circular padding, leaky-relu, 1-bit gate mask: forward, gated dgrad, wgrad; fp32 and 16-bit-operand kernels; last dispatch of each kernel',
+here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sha = {}
+for f in ('conv3x3_mfma.hip', 'conv3x3_h16.hip', 'conv3x3_wgrad.hip', 'conv3x3_wgrad_h16.hip', 'decoder_fused.hip'):
+    try:
+        sha[f] = hashlib.sha256(open(os.path.join(here, 'scm_gan_amd', 'csrc', f), 'rb').read()).hexdigest()[:16]
+    except OSError:
+        pass
+try:
+    commit = subprocess.run(['git', 'rev-parse', '--short', 'HEAD'], cwd=here, capture_output=True, text=True).stdout.strip() or None
+except Exception:
+    commit = None
+json.dump({'kernel_source_sha16': sha, 'git_commit': commit or os.environ.get('SCM_GIT_COMMIT'), 'source': 'rocprofv3 --kernel-trace --pmc <FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE> -- python3 tools/prof_hot2.py (separate passes)',
+           'case': '128->128 channels, B=64, 64x64, circular padding, leaky-relu, 1-bit gate mask: forward, gated dgrad, wgrad; fp32 and 16-bit-operand kernels; fused decoder + BCE forward / backward at B=64, 64x64x3; last dispatch of each kernel',
            'kernels': out}, sys.stdout, indent=1)

@@ -28,3 +28,12 @@ for mode in ('fp32', 'fp16'):
         else:
             L.check(lib.scm_conv3x3_wgrad(ctypes.byref(d), S()), 'wgrad')
     torch.cuda.synchronize()
+# the fused decoder + BCE launches of one unrolled step (fp32): forward, backward, at the bench batch
+ops.set_compute_precision('fp32')
+from scm_gan_amd import models as M
+dec = M.Decoder(16, 3)
+z = (torch.rand(B, 16, H, W, device='cuda') < 0.5).float().requires_grad_(True)
+tgt = (torch.rand(B, 3, H, W, device='cuda') < 0.1).float()
+for _ in range(3):
+    dec.forward_loss(z, tgt).mean().backward()
+torch.cuda.synchronize()
