@@ -90,6 +90,10 @@ typedef struct scm_conv3x3_desc {
      *                   keep reading gate1, which must still be passed.
      * A gradient convolution then loads one word per pixel and 32 channels instead of 32 floats. */
     uint32_t* gate_mask_out; const uint32_t* gate_mask_in;
+    /* != 0: y1 += out instead of y1 = out (y2 is always overwritten).  An activation with two consumers (the U-net
+     * skips of models.py:78,82 feeding conv2/conv6 and conv3/conv5) gets the second consumer's input gradient added
+     * in the epilogue of that consumer's gradient convolution instead of by a separate elementwise add. */
+    int32_t accumulate_y1;
 } scm_conv3x3_desc;
 
 int scm_conv3x3(const scm_conv3x3_desc* d, void* stream);

@@ -30,6 +30,7 @@ class ConvDesc(ctypes.Structure):
         ("B", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32),
         ("pad_mode", ctypes.c_int32), ("act", ctypes.c_int32),
         ("gate_mask_out", ctypes.c_void_p), ("gate_mask_in", ctypes.c_void_p),
+        ("accumulate_y1", ctypes.c_int32),
     ]
 
 

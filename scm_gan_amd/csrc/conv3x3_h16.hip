@@ -297,12 +297,15 @@ __global__ void __launch_bounds__(256, 1) conv3x3_h16_kernel(const ConvKArgs a) 
             if (co < a.cout) {
                 float* dst = (co < a.co1 ? a.y1 + ((size_t)b * a.co1 + co) * HW
                                          : a.y2 + ((size_t)b * co2n + (co - a.co1)) * HW) + p;
+                const bool add = a.acc_y1 && co < a.co1;
                 if (vec && p + 3 < HW) {
-                    *reinterpret_cast<f32x4*>(dst) = v;
+                    f32x4 o = v;
+                    if (add) o += *reinterpret_cast<const f32x4*>(dst);
+                    *reinterpret_cast<f32x4*>(dst) = o;
                 } else {
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        if (p + i < HW) dst[i] = v[i];
+                        if (p + i < HW) dst[i] = add ? dst[i] + v[i] : v[i];
                 }
             }
         }
@@ -473,6 +476,7 @@ extern "C" int scm_conv3x3_h16(const scm_conv3x3_desc* d, int precision, void* s
     k.wpack = d->wpack; k.cout = d->cout;
     k.scale = d->scale; k.bias = d->bias; k.sbias = d->sbias;
     k.y1 = d->y1; k.y2 = d->y2; k.co1 = d->co1;
+    k.acc_y1 = d->accumulate_y1;
     k.B = d->B; k.H = d->H; k.W = d->W; k.pad_mode = d->pad_mode; k.act = d->act;
     k.tiles_per_img = 0; k.plane = 0;
     k.mask_in = d->gate_mask_in;

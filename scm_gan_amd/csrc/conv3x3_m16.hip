@@ -189,7 +189,10 @@ __global__ void __launch_bounds__(256, 2) conv3x3_m16_kernel(const ConvKArgs a) 
 #pragma unroll
             for (int t = 0; t < M16_PT; ++t) {
                 const int p = p0 + wave * NPW + t * 16 + l15;
-                if (p < HW) dst[p] = scm_act(acc[t][r] * sc + badd[r], a.act);
+                if (p < HW) {
+                    const float v = scm_act(acc[t][r] * sc + badd[r], a.act);
+                    dst[p] = (a.acc_y1 && co < a.co1) ? dst[p] + v : v;
+                }
             }
         }
     }

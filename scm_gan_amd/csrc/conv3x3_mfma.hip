@@ -301,12 +301,15 @@ __global__ void __launch_bounds__(256, WPS) conv3x3_mfma_kernel(const ConvKArgs 
                 if (co < a.cout) {
                     float* dst = (co < a.co1 ? a.y1 + ((size_t)b * a.co1 + co) * HW
                                              : a.y2 + ((size_t)b * co2n + (co - a.co1)) * HW) + p;
+                    const bool add = a.acc_y1 && co < a.co1;
                     if (vec && p + 3 < HW) {
-                        *reinterpret_cast<f32x4*>(dst) = v;
+                        f32x4 o = v;
+                        if (add) o += *reinterpret_cast<const f32x4*>(dst);
+                        *reinterpret_cast<f32x4*>(dst) = o;
                     } else {
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
-                            if (p + i < HW) dst[i] = v[i];
+                            if (p + i < HW) dst[i] = add ? dst[i] + v[i] : v[i];
                     }
                 }
             }
@@ -348,7 +351,10 @@ __global__ void __launch_bounds__(256, WPS) conv3x3_mfma_kernel(const ConvKArgs 
 #pragma unroll
                 for (int n = 0; n < PT; ++n) {
                     const int p = pbase + n * 32;
-                    if (p < HW) dst[p] = scm_act(acc[m][n][r] * sc + badd[m][r], a.act);
+                    if (p < HW) {
+                        const float v = scm_act(acc[m][n][r] * sc + badd[m][r], a.act);
+                        dst[p] = (a.acc_y1 && co < a.co1) ? dst[p] + v : v;
+                    }
                 }
             }
         }
@@ -511,6 +517,7 @@ extern "C" int scm_conv3x3(const scm_conv3x3_desc* d, void* stream) {
     k.B = d->B; k.H = d->H; k.W = d->W; k.pad_mode = d->pad_mode; k.act = d->act;
     k.tiles_per_img = 0; k.plane = 0;
     k.mask_in = d->gate_mask_in;
+    k.acc_y1 = d->accumulate_y1;
     k.mask_out = (d->act == SCM_ACT_LRELU && d->cout > 32) ? d->gate_mask_out : nullptr;
     SCM_REQUIRE(!d->gate_mask_out || k.mask_out, "scm_conv3x3: gate_mask_out needs act == LRELU and cout > 32");
     if (d->cout <= 16) return scm_launch_conv3x3_m16(k, (hipStream_t)stream);

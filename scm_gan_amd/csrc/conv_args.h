@@ -15,6 +15,7 @@ struct ConvKArgs {
     int pad_mode; int act;
     int tiles_per_img; int plane;
     const unsigned* mask_in; unsigned* mask_out;   // 1-bit leaky-relu gate, words [B][ceil(C/32)][HW] (scm_hip.h)
+    int acc_y1;                                    // y1 += result (a second consumer's input gradient lands in the same buffer)
 };
 
 

@@ -54,10 +54,11 @@ class Conv2d(nn.Module):
             self._pack_key = key
         return self._packs
 
-    def forward(self, x, x2=None, act_vec=None, act=ops.ACT_NONE, _sn=None):
+    def forward(self, x, x2=None, act_vec=None, act=ops.ACT_NONE, _sn=None, dx1_cell=None, dx2_cell=None):
         """x (and optionally x2, concatenated along channels without being
         materialised); act_vec: (B, A) values of A trailing constant input planes
-        (circular 3x3 only).  _sn = (weight_bar, u, v, inv_sigma) from SpectralNorm."""
+        (circular 3x3 only).  _sn = (weight_bar, u, v, inv_sigma) from SpectralNorm.
+        dx1_cell / dx2_cell: shared-gradient cells of x / x2 (ops.SharedGradFork)."""
         if _sn is not None:
             w, u, v, inv_sigma = _sn
         else:
@@ -67,7 +68,7 @@ class Conv2d(nn.Module):
             if act_vec is not None and self.padding_mode != "circular":
                 raise ValueError("constant action planes fold into a bias only under circular padding")
             cfg = {"pad": ops.PAD_CIRCULAR if self.padding_mode == "circular" else ops.PAD_ZERO, "act": act,
-                   "transposed": False, "packs": self._get_packs(w, cin_conv)}
+                   "transposed": False, "packs": self._get_packs(w, cin_conv), "dx1_cell": dx1_cell, "dx2_cell": dx2_cell}
             return ops.Conv3x3Fn.apply(x, x2, act_vec, w, self.bias, inv_sigma, u, v, cfg)
         if x2 is not None or act_vec is not None:
             raise ValueError("two-input / action-plane forms need the 3x3 same-size geometry")

@@ -65,11 +65,23 @@ class Transition(nn.Module):
         L = ops.ACT_LRELU
         # the action planes (models.py:68-73) enter conv1 as a per-sample bias
         skip1 = self.conv1(s, None, a, act=L)
-        skip2 = self.conv2(skip1, act=L)
-        out3 = self.conv3(skip2, act=L)
-        out4 = self.conv4(out3, act=L)
-        out5 = self.conv5(out4, skip2, act=L)                 # cat([x, skip2]) never materialised
-        p = self.conv6(out5, skip1, act=ops.ACT_SIGMOID)      # cat([x, skip1])
+        if torch.is_grad_enabled() and skip1.requires_grad and os.environ.get("SCM_NO_SHARED_GRAD", "0") in ("", "0"):
+            # the two U-net skips have two consumers each (models.py:78-101): their gradients meet in one buffer
+            # inside the gradient convolutions (ops.SharedGradFork) instead of in an elementwise add
+            c1, c2 = {}, {}
+            s1a, s1b = ops.SharedGradFork.apply(skip1, c1)
+            skip2 = self.conv2(s1a, act=L, dx1_cell=c1)
+            s2a, s2b = ops.SharedGradFork.apply(skip2, c2)
+            out3 = self.conv3(s2a, act=L, dx1_cell=c2)
+            out4 = self.conv4(out3, act=L)
+            out5 = self.conv5(out4, s2b, act=L, dx2_cell=c2)      # cat([x, skip2]) never materialised
+            p = self.conv6(out5, s1b, act=ops.ACT_SIGMOID, dx2_cell=c1)   # cat([x, skip1])
+        else:
+            skip2 = self.conv2(skip1, act=L)
+            out3 = self.conv3(skip2, act=L)
+            out4 = self.conv4(out3, act=L)
+            out5 = self.conv5(out4, skip2, act=L)
+            p = self.conv6(out5, skip1, act=ops.ACT_SIGMOID)
         if self.training:
             if self._noise_queue:
                 x = ops.BernoulliSTFn.apply(p, self._noise_queue.pop(0), 1, 0, 0)

@@ -129,14 +129,16 @@ use_gate_mask = os.environ.get("SCM_NO_GATE_MASK", "0") in ("", "0")
 
 
 def _conv3x3_raw(x1, x2, gate1, gate2, gate_act, wpack, cout, scale, bias, sbias, co1, pad, act, prec=0,
-                 mask_out=None, mask_in=None):
+                 mask_out=None, mask_in=None, y1_acc=None):
+    """y1_acc: an existing (B, co1, H, W) tensor the first co1 output channels are ADDED to (accumulate_y1)."""
     lib = L.lib()
     B, c1, H, W = x1.shape
     c2 = 0 if x2 is None else x2.shape[1]
-    y1 = _new(x1, B, co1, H, W)
+    y1 = _new(x1, B, co1, H, W) if y1_acc is None else y1_acc
     y2 = _new(x1, B, cout - co1, H, W) if co1 < cout else None
     d = L.ConvDesc(_p(x1), _p(x2), c1, c2, _p(gate1), _p(gate2), gate_act, _p(wpack), cout, _p(scale), _p(bias),
-                   _p(sbias), _p(y1), _p(y2), co1, B, H, W, pad, act, _p(mask_out), _p(mask_in))
+                   _p(sbias), _p(y1), _p(y2), co1, B, H, W, pad, act, _p(mask_out), _p(mask_in),
+                   0 if y1_acc is None else 1)
     if kernel_timer is not None:
         ev = kernel_timer.bracket(conv_kernel_name(cout, prec), 2.0 * B * H * W * cout * (c1 + c2) * 9)
         ev[0].record()
@@ -275,8 +277,20 @@ class Conv3x3Fn(Function):
         need_x1, need_x2, need_a, need_w, need_b = ctx.needs_input_grad[:5]
         dx1 = dx2 = d_act = dw = db = None
         if need_x1 or need_x2:
+            # an input with a second consumer (SharedGradFork): whichever consumer's backward runs first leaves its
+            # input gradient in the shared cell, the other adds into that buffer in its gradient conv's epilogue
+            cell1, cell2 = cfg.get("dx1_cell"), cfg.get("dx2_cell")
+            acc1 = cell1.get("buf") if cell1 is not None else None
             dx1, dx2 = _conv3x3_raw(gy, None, y if act else None, None, act, dpack, c1 + c2, inv_sigma, None, None, c1,
-                                    cfg["pad"], ACT_NONE, ctx.dprec, mask_in=ctx.mask)
+                                    cfg["pad"], ACT_NONE, ctx.dprec, mask_in=ctx.mask, y1_acc=acc1)
+            if cell1 is not None:
+                cell1["buf"] = dx1
+            if cell2 is not None and dx2 is not None:
+                if cell2.get("buf") is None:
+                    cell2["buf"] = dx2
+                else:                       # (not the order autograd produces for the transition; kept correct)
+                    cell2["buf"].add_(dx2)
+                    dx2 = cell2["buf"]
         if need_w or need_b or need_a:
             pf, cf = ctypes.c_size_t(), ctypes.c_size_t()
             L.check(lib.scm_conv3x3_wgrad_workspace(B, H, W, c1 + c2, cout, ctypes.byref(pf), ctypes.byref(cf)),
@@ -320,6 +334,27 @@ class Conv3x3Fn(Function):
                 db = None
         return (dx1 if need_x1 else None, dx2 if need_x2 else None, d_act if need_a else None,
                 dw if need_w else None, db if need_b else None, None, None, None, None)
+
+
+class SharedGradFork(Function):
+    """x -> (x, x) for an activation with two convolution consumers.  `cell` is the dict the two consumers were
+    given as dx1_cell / dx2_cell: their backward passes write / accumulate the input gradient into ONE buffer
+    (scm_conv3x3_desc.accumulate_y1), so the sum autograd would compute with an elementwise add kernel (a 128-channel
+    map read twice and written once) never runs.  Falls back to that add when the gradients arrive separately."""
+
+    @staticmethod
+    def forward(ctx, x, cell):
+        ctx.cell = cell
+        return x.view_as(x), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        ctx.cell.pop("buf", None)
+        if g1 is None or g2 is None:
+            return (g1 if g2 is None else g2), None
+        if g1.data_ptr() == g2.data_ptr():
+            return g1, None
+        return g1 + g2, None
 
 
 # ------------------------------------------------------------ small conv
