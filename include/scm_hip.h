@@ -229,9 +229,11 @@ int scm_conv2d_bwd(const scm_conv2d_desc* d, const float* dy, float* dx, float* 
  * ---------------------------------------------------------------------- */
 /* DifferentiableBernoulliSampler forward / eval threshold (models.py:30-40,
  * 107-113). mode 0: out = (p > 0.5); mode 1: out = (noise < p); mode 2:
- * out = (philox4x32(seed, offset + i/4) < p). Backward is the identity. */
+ * out = (philox4x32(seed, offset + *offset_dev + i/4) < p). Backward is the identity.
+ * offset_dev (may be NULL): a device-resident part of the stream position -- what lets a captured iteration
+ * (HIP graph, whose kernel arguments are frozen) draw fresh noise on every replay. */
 int scm_bernoulli(const float* p, const float* noise, float* out, size_t n, int mode, uint64_t seed,
-                  uint64_t offset, void* stream);
+                  uint64_t offset, const uint64_t* offset_dev, void* stream);
 
 /* Decoder factor sum x.view(B,L,C,H,W).sum(1) (models.py:280-287) and its
  * backward (broadcast over L). */
@@ -271,12 +273,14 @@ int scm_linear_bwd(const float* x, const float* w, const float* y, const float* 
 /* Loss bookkeeping of one unrolled step (main.py:178-197): mask_out = mask_in * (1 - done);
  * loss_out = loss_in + coef * rd + rec, rd_rec = { rd, rec } with rd = mean_b(mean_r((rhat-r)^2) * mask_out),
  * rec = mean_b(bce * mask_out); r / done are columns of (B,T,R) / (B,T) tensors (element strides
- * given; loss_in may be NULL).  _bwd: gradients w.r.t. rhat and bce for upstream scalar g. */
+ * given; loss_in may be NULL).  _bwd: gradients w.r.t. rhat and bce for upstream scalar g.
+ * coef_dev (may be NULL) overrides coef with a device-resident value (theta changes per iteration, a captured
+ * iteration reads it from memory). */
 int scm_step_loss(const float* rhat, const float* r, long r_stride, const float* done, long done_stride,
                   const float* bce, const float* mask_in, const float* loss_in, int B, int R, float coef,
-                  float* mask_out, float* loss_out, float* rd_rec, void* stream);
+                  const float* coef_dev, float* mask_out, float* loss_out, float* rd_rec, void* stream);
 int scm_step_loss_bwd(const float* rhat, const float* r, long r_stride, const float* mask, const float* g, int B,
-                      int R, float coef, float* d_rhat, float* d_bce, void* stream);
+                      int R, float coef, const float* coef_dev, float* d_rhat, float* d_bce, void* stream);
 
 /* onehot(a_idx, num_actions) (main.py:447-452) on the device: out[n][num_actions], out[i][a] = (idx[i] == a);
  * idx are int64 action indices already resident on the device (device batch interface). */
@@ -289,10 +293,11 @@ int scm_coord_cat(const float* x, float* out, int B, int C, int H, int W, void* 
  * 287-296). grads are first multiplied by grad_scale (1/world_size after a sum
  * all-reduce), clamped to [-clip, clip] when clip_value > 0 (stored back, as
  * clip_grad_value_ does), then m, v, p are updated with bias correction for
- * `step` (1-based). Pointer tables are HOST arrays of device pointers. */
+ * `step` (1-based), or for *step_dev when that device pointer is given (captured iterations). The bias
+ * corrections are computed on the device in both forms. Pointer tables are HOST arrays of device pointers. */
 int scm_adam_clip_multi(int count, float* const* params, float* const* grads, float* const* exp_avg,
                         float* const* exp_avg_sq, const int* numel, float lr, float beta1, float beta2, float eps,
-                        int step, float clip_value, float grad_scale, void* stream);
+                        int step, const int* step_dev, float clip_value, float grad_scale, void* stream);
 
 /* ------------------------------------------------------------------------
  * CSRN directional sweep (spatial_recurrent.py:55-114): per image row (along_rows

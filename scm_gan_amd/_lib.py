@@ -127,7 +127,7 @@ def lib():
             "scm_conv2d_fwd": [vp, vp],
             "scm_conv2d_bwd": [vp, vp, vp, vp, vp, ci, vp, vp],
             "scm_conv2d_bwd_workspace": [ci, ci, ci, ci],
-            "scm_bernoulli": [vp, vp, vp, st, ci, u64, u64, vp],
+            "scm_bernoulli": [vp, vp, vp, st, ci, u64, u64, vp, vp],
             "scm_factor_sum": [vp, vp, ci, ci, ci, ci, vp],
             "scm_factor_bcast": [vp, vp, ci, ci, ci, ci, vp],
             "scm_pixel_loss": [vp, vp, ci, ci, ci, vp, vp, vp],
@@ -139,12 +139,12 @@ def lib():
             "scm_linear": [vp, vp, vp, ci, ci, ci, ci, vp, vp],
             "scm_linear_bwd": [vp, vp, vp, vp, ci, ci, ci, ci, vp, vp, vp, vp],
             "scm_coord_cat": [vp, vp, ci, ci, ci, ci, vp],
-            "scm_step_loss": [vp, vp, ctypes.c_long, vp, ctypes.c_long, vp, vp, vp, ci, ci, cf, vp, vp, vp, vp],
-            "scm_step_loss_bwd": [vp, vp, ctypes.c_long, vp, vp, ci, ci, cf, vp, vp, vp],
+            "scm_step_loss": [vp, vp, ctypes.c_long, vp, ctypes.c_long, vp, vp, vp, ci, ci, cf, vp, vp, vp, vp, vp],
+            "scm_step_loss_bwd": [vp, vp, ctypes.c_long, vp, vp, ci, ci, cf, vp, vp, vp, vp],
             "scm_onehot": [vp, ctypes.c_long, ci, vp, vp],
             "scm_csrn_sweep_fwd": [vp, vp],
             "scm_csrn_sweep_bwd": [vp, vp, vp, vp, vp, vp],
-            "scm_adam_clip_multi": [ci, vp, vp, vp, vp, vp, cf, cf, cf, cf, ci, cf, cf, vp],
+            "scm_adam_clip_multi": [ci, vp, vp, vp, vp, vp, cf, cf, cf, cf, ci, vp, cf, cf, vp],
             "scm_decoder_fused_pack_floats": [],
             "scm_decoder_fused_pack": [vp, vp, vp, vp, ci, ci, vp, vp],
             "scm_decoder_fused_workspace": [ci, ci, ci, ci, vp, vp],

@@ -17,7 +17,13 @@ struct AdamTable {
 };
 
 __global__ void __launch_bounds__(256) adam_clip_kernel(const AdamTable t, float lr, float b1, float b2, float eps,
-                                                        float bc1, float bc2_sqrt, float clip, float grad_scale) {
+                                                        int step_v, const int* __restrict__ step_dev, float clip,
+                                                        float grad_scale) {
+    // bias corrections from the step number, by value or from device memory (a captured iteration keeps its
+    // step counter on the device); computed here in both cases so the two launch forms give the same bits
+    const float stepf = (float)(step_dev ? *step_dev : step_v);
+    const float bc1 = 1.f - powf(b1, stepf);
+    const float bc2_sqrt = sqrtf(1.f - powf(b2, stepf));
     const int k = blockIdx.y;
     const int n = t.n[k];
     float* p = t.p[k]; float* g = t.g[k]; float* m = t.m[k]; float* v = t.v[k];
@@ -36,11 +42,10 @@ __global__ void __launch_bounds__(256) adam_clip_kernel(const AdamTable t, float
 
 extern "C" int scm_adam_clip_multi(int count, float* const* params, float* const* grads, float* const* exp_avg,
                                    float* const* exp_avg_sq, const int* numel, float lr, float beta1, float beta2,
-                                   float eps, int step, float clip_value, float grad_scale, void* stream) {
+                                   float eps, int step, const int* step_dev, float clip_value, float grad_scale,
+                                   void* stream) {
     SCM_REQUIRE(count >= 0 && params && grads && exp_avg && exp_avg_sq && numel, "scm_adam_clip_multi: bad arguments");
-    SCM_REQUIRE(step >= 1, "scm_adam_clip_multi: step counts from 1");
-    const float bc1 = 1.f - powf(beta1, (float)step);
-    const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
+    SCM_REQUIRE(step_dev || step >= 1, "scm_adam_clip_multi: step counts from 1");
     for (int base = 0; base < count; base += ADAM_MAX_TENSORS) {
         AdamTable t;
         int c = count - base;
@@ -59,7 +64,7 @@ extern "C" int scm_adam_clip_multi(int count, float* const* params, float* const
         int bx = (maxn + 255) / 256;
         if (bx > 256) bx = 256;
         hipLaunchKernelGGL(adam_clip_kernel, dim3(bx, c), dim3(256), 0, (hipStream_t)stream, t, lr, beta1, beta2, eps,
-                           bc1, bc2_sqrt, clip_value, grad_scale);
+                           step, step_dev, clip_value, grad_scale);
         SCM_LAUNCH_CHECK("adam_clip_kernel");
     }
     return SCM_OK;

@@ -25,12 +25,13 @@ __device__ __forceinline__ float u01(uint32_t x) { return (x >> 8) * (1.0f / 167
 // z' = DifferentiableBernoulliSampler / eval threshold, models.py:30-40,107-113.
 //   mode 0: (p > 0.5)      mode 1: (noise < p), noise given      mode 2: (philox < p)
 __global__ void bernoulli_kernel(const float* __restrict__ p, const float* __restrict__ noise, float* __restrict__ out,
-                                 size_t n, int mode, uint64_t seed, uint64_t offset) {
+                                 size_t n, int mode, uint64_t seed, uint64_t offset,
+                                 const uint64_t* __restrict__ offset_dev) {
     const size_t i4 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i4 >= n) return;
     float u[4] = {0.5f, 0.5f, 0.5f, 0.5f};
     if (mode == 2) {
-        const uint64_t ctr = offset + i4 / 4;
+        const uint64_t ctr = offset + (offset_dev ? *offset_dev : 0) + i4 / 4;
         uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
         philox4x32(c, (uint32_t)seed, (uint32_t)(seed >> 32));
 #pragma unroll
@@ -48,12 +49,12 @@ __global__ void bernoulli_kernel(const float* __restrict__ p, const float* __res
 }
 
 extern "C" int scm_bernoulli(const float* p, const float* noise, float* out, size_t n, int mode, uint64_t seed,
-                             uint64_t offset, void* stream) {
+                             uint64_t offset, const uint64_t* offset_dev, void* stream) {
     SCM_REQUIRE(p && out && n > 0 && mode >= 0 && mode <= 2, "scm_bernoulli: bad arguments");
     SCM_REQUIRE(mode != 1 || noise, "scm_bernoulli: mode 1 needs the noise tensor");
     const size_t threads = (n + 3) / 4;
     hipLaunchKernelGGL(bernoulli_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p,
-                       noise, out, n, mode, seed, offset);
+                       noise, out, n, mode, seed, offset, offset_dev);
     SCM_LAUNCH_CHECK("bernoulli_kernel");
     return SCM_OK;
 }
@@ -409,9 +410,11 @@ __global__ void __launch_bounds__(256) step_loss_kernel(const float* __restrict_
                                                         long r_stride, const float* __restrict__ done,
                                                         long done_stride, const float* __restrict__ bce,
                                                         const float* __restrict__ mask_in, const float* loss_in,
-                                                        int B, int R, float coef, float* __restrict__ mask_out,
+                                                        int B, int R, float coef_v, const float* coef_dev,
+                                                        float* __restrict__ mask_out,
                                                         float* __restrict__ loss_out, float* __restrict__ rd_rec) {
     __shared__ float red[4];
+    const float coef = coef_dev ? *coef_dev : coef_v;
     float srd = 0.f, srec = 0.f;
     for (int b = threadIdx.x; b < B; b += 256) {
         const float m = mask_in[b] * (1.f - done[(size_t)b * done_stride]);
@@ -436,9 +439,11 @@ __global__ void __launch_bounds__(256) step_loss_kernel(const float* __restrict_
 // d rhat[b][k] = g * coef * 2 (rhat - r) / (R B) * mask;  d bce[b] = g * mask / B
 __global__ void step_loss_bwd_kernel(const float* __restrict__ rhat, const float* __restrict__ r, long r_stride,
                                      const float* __restrict__ mask, const float* __restrict__ g, int B, int R,
-                                     float coef, float* __restrict__ d_rhat, float* __restrict__ d_bce) {
+                                     float coef_v, const float* coef_dev, float* __restrict__ d_rhat,
+                                     float* __restrict__ d_bce) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= B * R) return;
+    const float coef = coef_dev ? *coef_dev : coef_v;
     const int b = idx / R, k = idx - b * R;
     const float gg = *g, m = mask[b];
     d_rhat[idx] = gg * coef * 2.f * (rhat[idx] - r[(size_t)b * r_stride + k]) / (float)(R * B) * m;
@@ -446,19 +451,20 @@ __global__ void step_loss_bwd_kernel(const float* __restrict__ rhat, const float
 }
 extern "C" int scm_step_loss(const float* rhat, const float* r, long r_stride, const float* done, long done_stride,
                              const float* bce, const float* mask_in, const float* loss_in, int B, int R, float coef,
-                             float* mask_out, float* loss_out, float* rd_rec, void* stream) {
+                             const float* coef_dev, float* mask_out, float* loss_out, float* rd_rec, void* stream) {
     SCM_REQUIRE(rhat && r && done && bce && mask_in && mask_out && loss_out && rd_rec && B > 0 && R > 0,
                 "scm_step_loss: bad arguments");
     hipLaunchKernelGGL(step_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, rhat, r, r_stride, done,
-                       done_stride, bce, mask_in, loss_in, B, R, coef, mask_out, loss_out, rd_rec);
+                       done_stride, bce, mask_in, loss_in, B, R, coef, coef_dev, mask_out, loss_out, rd_rec);
     SCM_LAUNCH_CHECK("step_loss_kernel");
     return SCM_OK;
 }
 extern "C" int scm_step_loss_bwd(const float* rhat, const float* r, long r_stride, const float* mask, const float* g,
-                                 int B, int R, float coef, float* d_rhat, float* d_bce, void* stream) {
+                                 int B, int R, float coef, const float* coef_dev, float* d_rhat, float* d_bce,
+                                 void* stream) {
     SCM_REQUIRE(rhat && r && mask && g && d_rhat && d_bce && B > 0 && R > 0, "scm_step_loss_bwd: bad arguments");
     hipLaunchKernelGGL(step_loss_bwd_kernel, dim3((B * R + 255) / 256), dim3(256), 0, (hipStream_t)stream, rhat, r,
-                       r_stride, mask, g, B, R, coef, d_rhat, d_bce);
+                       r_stride, mask, g, B, R, coef, coef_dev, d_rhat, d_bce);
     SCM_LAUNCH_CHECK("step_loss_bwd_kernel");
     return SCM_OK;
 }

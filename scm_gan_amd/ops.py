@@ -28,6 +28,17 @@ def bump_weights_epoch():
     _weights_epoch[0] += 1
 
 
+# Device-resident per-iteration scalars of a captured training iteration (graph_step.GraphedTrainer sets them
+# while it captures): 'coef' float32[1] (theta * reward_coef), 'noise_off' int64[1] (Philox stream position),
+# 'adam_step' int32[1].  Empty in eager mode: the same values then travel by value.
+dev_scalars = {}
+
+
+def _dev(name):
+    t = dev_scalars.get(name)
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
 def _chk(t, name):
     if t is None:
         return None
@@ -407,8 +418,8 @@ class BernoulliSTFn(Function):
         p = _chk(p, "bernoulli")
         noise = _chk(noise, "bernoulli")
         out = torch.empty_like(p)
-        L.check(L.lib().scm_bernoulli(_p(p), _p(noise), _p(out), p.numel(), mode, seed, offset, _stream()),
-                "scm_bernoulli")
+        L.check(L.lib().scm_bernoulli(_p(p), _p(noise), _p(out), p.numel(), mode, seed, offset,
+                                      _dev("noise_off") if mode == 2 else None, _stream()), "scm_bernoulli")
         return out
 
     @staticmethod
@@ -420,7 +431,7 @@ def threshold(p):
     """Eval-mode latent: (p > 0.5), models.py:110-113 (no gradient)."""
     p = _chk(p.detach(), "threshold")
     out = torch.empty_like(p)
-    L.check(L.lib().scm_bernoulli(_p(p), None, _p(out), p.numel(), 0, 0, 0, _stream()), "scm_bernoulli")
+    L.check(L.lib().scm_bernoulli(_p(p), None, _p(out), p.numel(), 0, 0, 0, None, _stream()), "scm_bernoulli")
     return out
 
 
@@ -429,8 +440,8 @@ def bernoulli_sample(p, seed, offset):
     is fed (models.py:18,193-199) are bernoulli_sample(0.5)."""
     p = _chk(p.detach(), "bernoulli_sample")
     out = torch.empty_like(p)
-    L.check(L.lib().scm_bernoulli(_p(p), None, _p(out), p.numel(), 2, int(seed), int(offset), _stream()),
-            "scm_bernoulli")
+    L.check(L.lib().scm_bernoulli(_p(p), None, _p(out), p.numel(), 2, int(seed), int(offset), _dev("noise_off"),
+                                  _stream()), "scm_bernoulli")
     return out
 
 
@@ -736,8 +747,10 @@ class StepLossFn(Function):
         lin = None if loss_in is None else _chk(loss_in, "step_loss")
         L.check(lib.scm_step_loss(_p(rhat), ctypes.c_void_p(rewards_t.data_ptr()), rewards_t.stride(0),
                                   ctypes.c_void_p(dones_t.data_ptr()), dones_t.stride(0), _p(bce), _p(mask_in),
-                                  _p(lin), B, R, coef, _p(mask_out), _p(loss_out), _p(rd_rec), _stream()), "scm_step_loss")
+                                  _p(lin), B, R, coef, _dev("coef"), _p(mask_out), _p(loss_out), _p(rd_rec), _stream()),
+                "scm_step_loss")
         ctx.coef = coef
+        ctx.coef_dev = dev_scalars.get("coef")
         ctx.has_loss_in = loss_in is not None
         ctx.save_for_backward(rhat, rewards_t, mask_out)
         rd, rec = rd_rec[0:1], rd_rec[1:2]
@@ -751,6 +764,6 @@ class StepLossFn(Function):
         g = _chk(g, "step_loss.backward")
         d_rhat, d_bce = torch.empty_like(rhat), _new(rhat, B)
         L.check(L.lib().scm_step_loss_bwd(_p(rhat), ctypes.c_void_p(rewards_t.data_ptr()), rewards_t.stride(0),
-                                          _p(mask), _p(g), B, R, ctx.coef, _p(d_rhat), _p(d_bce), _stream()),
-                "scm_step_loss_bwd")
+                                          _p(mask), _p(g), B, R, ctx.coef, _p(ctx.coef_dev), _p(d_rhat), _p(d_bce),
+                                          _stream()), "scm_step_loss_bwd")
         return (g if ctx.has_loss_in else None), d_rhat, d_bce, None, None, None, None

@@ -55,6 +55,8 @@ class AdamClip(object):
                 if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous()):
                     raise RuntimeError("AdamClip: parameters and grads must be contiguous fp32 GPU tensors")
             ns = (ctypes.c_int * n)(*[p.numel() for p, _ in items])
+            step_dev = ops.dev_scalars.get("adam_step")     # captured iteration: the step number lives on the device
             L.check(lib.scm_adam_clip_multi(n, ps, gs, ms, vs, ns, self.lr, self.betas[0], self.betas[1], self.eps,
-                                            step, self.clip_value, self.grad_scale, stream), "scm_adam_clip_multi")
+                                            step, None if step_dev is None else ctypes.c_void_p(step_dev.data_ptr()),
+                                            self.clip_value, self.grad_scale, stream), "scm_adam_clip_multi")
         ops.bump_weights_epoch()

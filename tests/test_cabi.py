@@ -44,8 +44,10 @@ def test_version_and_error_convention(lib):
     assert b"x1" in lib.scm_last_error()
     assert lib.scm_conv3x3_wgrad(None, None) == -1
     assert lib.scm_sn_power_iter(0, None, 1, None) == -1
-    assert lib.scm_bernoulli(None, None, None, 0, 0, 0, 0, None) == -1
-    assert lib.scm_adam_clip_multi(1, None, None, None, None, None, 1e-4, 0.9, 0.999, 1e-8, 1, 0.1, 1.0, None) == -1
+    assert lib.scm_bernoulli(None, None, None, 0, 0, 0, 0, None, None) == -1
+    assert lib.scm_adam_clip_multi(1, None, None, None, None, None, 1e-4, 0.9, 0.999, 1e-8, 1, None, 0.1, 1.0, None) == -1
+    assert lib.scm_decoder_fused_fwd(None, None) == -1 and lib.scm_decoder_fused_bwd(None, None) == -1
+    assert lib.scm_decoder_fused_pack(None, None, None, None, 16, 3, None, None) == -1
     with pytest.raises(RuntimeError):
         L.check(-1, "scm_conv3x3")
 
