@@ -67,6 +67,9 @@ parser.add_argument('--gan', action='store_true',
                          'iteration on (B, 3, 64, 64) U{0,1} noise maps (SURVEY.md 8(d) cfg3). The reference constructs the '
                          'discriminator and its optimizer (main.py:76,128) but defines NO GAN loss; the critic term here '
                          '(mean logit) is build-defined')
+parser.add_argument('--graph-step', action='store_true',
+                    help='replay the training iteration as one HIP graph per (batch shape, horizon) after two eager '
+                         'iterations of that shape (graph_step.GraphedTrainer; default loss, single process only)')
 parser.add_argument('--no-overlap', action='store_true',
                     help='data parallel: all-reduce every bucket after backward() instead of overlapping with it')
 parser.add_argument('--check-replicas', action='store_true',
@@ -341,6 +344,10 @@ def train(latent_dim, datasource, num_actions, num_rewards,
     batch_size = args.batch_size // world
     ts = trainer.ts
     nets = [encoder, decoder, transition, discriminator, reward_predictor]
+    stepper = trainer
+    if getattr(args, 'graph_step', False):
+        from .graph_step import GraphedTrainer
+        stepper = GraphedTrainer(trainer)
 
     def horizon_of(it):                                                        # main.py:143-145
         return args.horizon_min + int((args.horizon_max - args.horizon_min) * (it / train_iters))
@@ -372,10 +379,10 @@ def train(latent_dim, datasource, num_actions, num_rewards,
 
         if queue is not None:
             d_states, d_rewards, d_dones, d_onehot, actions = queue.get()
-            trainer.step(d_states, d_rewards, d_dones, d_onehot, theta, train_iter, actions)
+            stepper.step(d_states, d_rewards, d_dones, d_onehot, theta, train_iter, actions)
         else:
             states, rewards, dones, actions = datasource.get_trajectories(batch_size, prediction_horizon)
-            trainer.step(_upload(states), _upload(rewards), _upload(np.asarray(dones).astype(int)),
+            stepper.step(_upload(states), _upload(rewards), _upload(np.asarray(dones).astype(int)),
                          onehot(actions, num_actions), theta, train_iter, actions)
         if world > 1 and train_iter % args.log_every == 0:
             ts.all_reduce_latest(world)        # the logged losses are local-batch means: average them over the ranks
