@@ -374,6 +374,25 @@ typedef struct scm_decoder_fused_bwd_desc {
 
 int scm_decoder_fused_bwd(const scm_decoder_fused_bwd_desc* d, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Fused reward-head convolutions: RewardPredictor.conv1 (16 -> 32, 3x3 valid) + leaky_relu + conv2 (32 -> Q = 3R,
+ * 3x3, stride 2, valid), models.py:235-240, in one pass over the latent; the 32-channel hidden map stays on chip.
+ * The softmax tail (models.py:241-250) is scm_reward_tail on the result.  latent_dim 16, Q <= 6, frames 5..64 wide.
+ *   pack : scm_reward_fused_pack_floats() floats from conv1.weight (32,16,3,3), conv1.bias, conv2.weight (Q,32,3,3),
+ *          conv2.bias (nn.Conv2d layouts); rebuild when they change.
+ *   fwd  : o[B][Q][OH][OW], OH = (H-5)/2 + 1, OW = (W-5)/2 + 1.
+ *   bwd  : from d_o (gradient of o): dz[B][16][H][W] and the four parameter gradients (accumulate != 0 adds into
+ *          them); workspace = scm_reward_fused_workspace() floats (per-workgroup slabs, fixed-order sum).
+ * ---------------------------------------------------------------------- */
+size_t scm_reward_fused_pack_floats(void);
+int scm_reward_fused_pack(const float* conv1_weight, const float* conv1_bias, const float* conv2_weight,
+                          const float* conv2_bias, int latent, int Q, float* pack, void* stream);
+int scm_reward_fused_workspace(int B, int H, int W, int Q, size_t* bwd_floats);
+int scm_reward_fused_fwd(const float* z, const float* pack, float* o, int B, int H, int W, int Q, void* stream);
+int scm_reward_fused_bwd(const float* z, const float* pack, const float* d_o, float* dz, float* d_conv1_weight,
+                         float* d_conv1_bias, float* d_conv2_weight, float* d_conv2_bias, float* workspace, int B, int H,
+                         int W, int Q, int accumulate, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -150,12 +150,18 @@ def lib():
             "scm_decoder_fused_workspace": [ci, ci, ci, ci, vp, vp],
             "scm_decoder_fused_fwd": [vp, vp],
             "scm_decoder_fused_bwd": [vp, vp],
+            "scm_reward_fused_pack_floats": [],
+            "scm_reward_fused_pack": [vp, vp, vp, vp, ci, ci, vp, vp],
+            "scm_reward_fused_workspace": [ci, ci, ci, ci, vp],
+            "scm_reward_fused_fwd": [vp, vp, vp, ci, ci, ci, ci, vp],
+            "scm_reward_fused_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp],
         }
         for name, args in sigs.items():
             fn = getattr(L, name)      # raises AttributeError when the library lacks a declared symbol
             fn.argtypes = args
             fn.restype = ctypes.c_size_t if name in ("scm_conv3x3_pack_floats", "scm_conv2d_bwd_workspace",
-                                                  "scm_conv3x3_pack_h16_bytes", "scm_decoder_fused_pack_floats") \
+                                                  "scm_conv3x3_pack_h16_bytes", "scm_decoder_fused_pack_floats",
+                                                  "scm_reward_fused_pack_floats") \
                 else ctypes.c_int
         L._scm_symbols = sorted(sigs) + ["scm_version", "scm_last_error"]
         _lib = L

@@ -147,8 +147,24 @@ class RewardPredictor(nn.Module):
         self.conv2 = Conv2d(32, num_rewards * 3, (3, 3), stride=2, padding=0)
         _to_gpu(self)
 
+    def _fused(self, x):
+        return x.shape[1] == 16 and self.num_rewards <= 2 and 5 <= x.shape[3] <= 64 and x.shape[2] >= 5 and \
+            ops.compute_precision() == "fp32" and os.environ.get("SCM_NO_FUSED_REWARD", "0") in ("", "0")
+
+    def _fused_pack(self):
+        ps = (self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias)
+        key = (ops.weights_epoch(),) + tuple((p.data_ptr(), p._version) for p in ps)
+        if getattr(self, "_fpack_key", None) != key:
+            self._fpack = ops.reward_fused_pack(*ps, 16)
+            self._fpack_key = key
+        return self._fpack
+
     def forward(self, x, visualize=False):
-        if x.shape[2] > 2 and x.shape[3] > 2:
+        if self._fused(x):
+            # both convolutions in one pass over z (scm_reward_fused_*), the 32-channel map stays on chip
+            x = ops.RewardConvFn.apply(x, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias,
+                                       self._fused_pack())
+        elif x.shape[2] > 2 and x.shape[3] > 2:
             # conv1 (valid 3x3) = interior of the same-size conv on the MFMA kernel; conv2 reads that
             # interior in place (padding -1): no crop copy forward, no zero-embed backward
             x = self.conv1.forward_same(x, act=ops.ACT_LRELU)

@@ -506,12 +506,15 @@ class RewardTailFn(Function):
         L.check(L.lib().scm_reward_tail(_p(x), B, R, h * w, _p(r), _p(m), _stream()), "scm_reward_tail")
         ctx.geom = (B, R, h, w)
         ctx.save_for_backward(x)
+        ctx.set_materialize_grads(False)        # an unused output (the map, usually) contributes no zero-filled gradient
         return r, m
 
     @staticmethod
     def backward(ctx, g_r, g_map):
         (x,) = ctx.saved_tensors
         B, R, h, w = ctx.geom
+        if g_r is None and g_map is None:
+            return None, None
         g_r = _chk(g_r, "reward_tail.backward")
         g_map = _chk(g_map, "reward_tail.backward")
         dx = torch.empty_like(x)
@@ -599,6 +602,7 @@ class DecoderLossFn(Function):
         ctx.params = (w1, b1, w2, b2)
         ctx.save_for_backward(z, target, logits, pack)
         ctx.mark_non_differentiable(logits)
+        ctx.set_materialize_grads(False)
         return loss, logits
 
     @staticmethod
@@ -624,6 +628,57 @@ class DecoderLossFn(Function):
         if acc:
             return dz, None, None, None, None, None, None, None
         return dz, None, grads[0], grads[1], grads[2], grads[3], None, None
+
+
+# ------------------------------------------------------ fused reward head
+def reward_fused_pack(w1, b1, w2, b2, latent):
+    lib = L.lib()
+    ts = [_chk(t.detach(), "reward_fused_pack") for t in (w1, b1, w2, b2)]
+    pack = _new(ts[0], lib.scm_reward_fused_pack_floats())
+    L.check(lib.scm_reward_fused_pack(_p(ts[0]), _p(ts[1]), _p(ts[2]), _p(ts[3]), latent, ts[2].shape[0], _p(pack),
+                                      _stream()), "scm_reward_fused_pack")
+    return pack
+
+
+class RewardConvFn(Function):
+    """conv2(leaky_relu(conv1(z))) of the reward head (models.py:235-240) in one pass (scm_reward_fused_fwd / _bwd):
+    z (B, 16, H, W) -> o (B, 3R, OH, OW).  The hidden map is recomputed in backward."""
+
+    @staticmethod
+    def forward(ctx, z, w1, b1, w2, b2, pack):
+        z = _chk(z, "reward_conv")
+        B, _, H, W = z.shape
+        Q = w2.shape[0]
+        o = _new(z, B, Q, (H - 5) // 2 + 1, (W - 5) // 2 + 1)
+        if kernel_timer is not None:
+            ev = kernel_timer.bracket("reward_fused_fwd", 2.0 * B * 9 * ((H - 2) * (W - 2) * 16 * 32 + o.shape[2] * o.shape[3] * 32 * Q))
+            ev[0].record()
+        L.check(L.lib().scm_reward_fused_fwd(_p(z), _p(pack), _p(o), B, H, W, Q, _stream()), "scm_reward_fused_fwd")
+        if kernel_timer is not None:
+            ev[1].record()
+        ctx.params = (w1, b1, w2, b2)
+        ctx.save_for_backward(z, pack)
+        return o
+
+    @staticmethod
+    def backward(ctx, g_o):
+        z, pack = ctx.saved_tensors
+        g_o = _chk(g_o, "reward_conv.backward")
+        B, _, H, W = z.shape
+        Q = g_o.shape[1]
+        sinks = [_grad_sink(p) for p in ctx.params]
+        acc = all(s is not None for s in sinks)
+        grads = sinks if acc else [torch.empty_like(p) for p in ctx.params]
+        dz = torch.empty_like(z)
+        n = ctypes.c_size_t()
+        L.check(L.lib().scm_reward_fused_workspace(B, H, W, Q, ctypes.byref(n)), "scm_reward_fused_workspace")
+        ws = _new(z, max(1, n.value))
+        L.check(L.lib().scm_reward_fused_bwd(_p(z), _p(pack), _p(g_o), _p(dz), _p(grads[0]), _p(grads[1]), _p(grads[2]),
+                                             _p(grads[3]), _p(ws), B, H, W, Q, 1 if acc else 0, _stream()),
+                "scm_reward_fused_bwd")
+        if acc:
+            return dz, None, None, None, None, None
+        return dz, grads[0], grads[1], grads[2], grads[3], None
 
 
 _mean_weights = {}
@@ -755,6 +810,7 @@ class StepLossFn(Function):
         ctx.save_for_backward(rhat, rewards_t, mask_out)
         rd, rec = rd_rec[0:1], rd_rec[1:2]
         ctx.mark_non_differentiable(mask_out, rd, rec)
+        ctx.set_materialize_grads(False)
         return loss_out, rd, rec, mask_out
 
     @staticmethod

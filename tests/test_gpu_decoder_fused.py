@@ -137,3 +137,48 @@ def test_four_channel_frames_take_the_layer_path():
         a = dec.forward_loss(z, tgt)
         b = ops.pixel_bce(dec(z), tgt)
     assert torch.equal(a, b)
+
+
+# ------------------------------------------------------------------ fused reward-head convolutions
+REWARD_SHAPES = [(2, 16, 16, 2), (1, 20, 12, 2), (3, 7, 13, 1), (2, 33, 20, 2), (2, 48, 64, 2), (1, 5, 5, 2), (2, 64, 31, 1),
+                 (4, 64, 64, 2)]
+
+
+@pytest.mark.parametrize("B,H,W,R", REWARD_SHAPES)
+def test_fused_reward_head_vs_oracle(B, H, W, R):
+    """scm_reward_fused_fwd / _bwd (RewardPredictor.conv1 + leaky_relu + conv2 in one pass, models.py:235-240) + the
+    softmax tail against the CPU oracle: r, the per-position map, dz and the four Conv2d gradients."""
+    from oracle import scm_oracle as O
+    from scm_gan_amd import models as M
+    seed = 11 * H + W
+    rng = np.random.default_rng(seed)
+    z = (rng.random((B, 16, H, W)) < 0.5).astype(np.float32)
+    gr = rng.standard_normal((B, R)).astype(np.float32)
+    ost = O.clone_state(WS.reward_state(seed, rewards=R))
+    for k in ost:
+        ost[k].requires_grad_(True)
+    oz = torch.from_numpy(z).requires_grad_(True)
+    orr, omap = O.reward_forward(ost, oz, visualize=True)
+    ((orr * torch.from_numpy(gr)).sum() + 0.01 * omap.sum()).backward()
+    rp = M.RewardPredictor(16, R)
+    rp.load_state_dict(WS.to_torch(WS.reward_state(seed, rewards=R)))
+    hz = dev(z).requires_grad_(True)
+    assert rp._fused(hz)
+    r, rmap = rp(hz, visualize=True)
+    ((r * dev(gr)).sum() + 0.01 * rmap.sum()).backward()
+    assert float((r.detach().cpu() - orr.detach()).abs().max()) < 1e-4 * max(1.0, float(orr.abs().max()))
+    assert float((rmap.detach().cpu() - omap.detach()).abs().max()) < 1e-5
+    pairs = [("dz", hz.grad, oz.grad)] + [(k, p.grad, ost[k].grad) for k, p in rp.named_parameters()]
+    for name, got, ref in pairs:
+        scale = max(1e-7, float(ref.abs().max()))
+        err = (got.cpu() - ref).abs()
+        bad = int((err > 1e-4 * scale + 1e-9).sum())
+        assert bad <= got.numel() // 20000, (name, float(err.max()), scale, bad)
+
+
+def test_wide_frames_keep_the_layer_path_for_the_reward_head():
+    from scm_gan_amd import models as M
+    rp = M.RewardPredictor(16, 1)
+    z = (torch.rand(1, 16, 20, 84, device="cuda") < 0.5).float()
+    assert not rp._fused(z)
+    assert rp(z).shape == (1, 1)
