@@ -209,11 +209,11 @@ class Trainer(object):
         # unrolled transition run on a side stream underneath the encoder's convolutions.
         # Sigmas an aborted iteration left queued are dropped first.
         SN.clear_precomputed([encoder, transition, self.discriminator])
-        SN.precompute([encoder] + ([self.discriminator] if self.gan else []), 1)
         main_stream = torch.cuda.current_stream()
-        self.side_stream.wait_stream(main_stream)
-        with torch.cuda.stream(self.side_stream):
+        self.side_stream.wait_stream(main_stream)           # (the previous iteration's Adam)
+        with torch.cuda.stream(self.side_stream):           # ~1.3 ms on 5 CUs, needed only after the encoder (~1.5 ms)
             SN.precompute([transition], prediction_horizon - 2)
+        SN.precompute([encoder] + ([self.discriminator] if self.gan else []), 1)
 
         z = encoder(states[:, 0:3])                                            # main.py:162
         self.sync.arm(z)
