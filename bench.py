@@ -332,13 +332,13 @@ def main():
 
     for i in range(a.warmup):
         trainer.step(*batches[i % 2], theta=0.5, train_iter=i + 1)
-    timer = None
-    if not a.no_kernel_timer and rank == 0:
-        timer = ops.KernelTimer()
-        ops.kernel_timer = timer
+    # HIP-event brackets around the MFMA conv launches (roofline): recorded on the launch stream inside the timed
+    # region, on every 5th step only -- two events per launch on all ~3000 launches cost 1.5 % of the step
+    timer = ops.KernelTimer() if (not a.no_kernel_timer and rank == 0) else None
     barrier()
     t0 = time.perf_counter()
     for i in range(a.steps):
+        ops.kernel_timer = timer if i % 5 == 0 else None
         trainer.step(*batches[i % 2], theta=0.5, train_iter=a.warmup + i + 1)
     barrier()
     dt = time.perf_counter() - t0
