@@ -482,12 +482,39 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wgrad_m16_kernel(const WgradKA
 // Sum the per-split slabs in split order and scatter into the torch layout.
 //   dw[co][ci][3][3]                    (transposed_dst == 0, nn.Conv2d)
 //   dw[ci][co][3][3] with taps flipped  (transposed_dst == 1, nn.ConvTranspose2d)
+// The last gridDim.x - nblk_w workgroups of the same launch reduce the per-sample channel sums (bias and action-plane
+// gradients): csum[b][co] = sum over the image's splits, db[co] = sum_b csum[b][co]; 64 co x 4 batch lanes each.
+struct CsumReduceArgs {
+    const float* csum_part; int B; int spi; int accumulate; float* csum; float* db;
+};
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ part, int nsplit, int cout,
                                                            int cin, int transposed_dst, int accumulate, int dct,
                                                            int dc0, float* __restrict__ dw,
                                                            const float* __restrict__ dot_w,
-                                                           float* __restrict__ dot_part) {
+                                                           float* __restrict__ dot_part, int nblk_w,
+                                                           const CsumReduceArgs cs) {
     __shared__ float red[4];
+    if ((int)blockIdx.x >= nblk_w) {
+        __shared__ float redc[4][64];
+        const int cl = threadIdx.x & 63, bl = threadIdx.x >> 6;
+        const int co = (blockIdx.x - nblk_w) * 64 + cl;
+        float tot = 0.f;
+        if (co < cout) {
+            for (int b = bl; b < cs.B; b += 4) {
+                float sb = 0.f;
+                for (int k = 0; k < cs.spi; ++k) sb += cs.csum_part[((size_t)b * cs.spi + k) * cout + co];
+                if (cs.csum) cs.csum[(size_t)b * cout + co] = sb;
+                tot += sb;
+            }
+        }
+        redc[bl][cl] = tot;
+        __syncthreads();
+        if (bl == 0 && co < cout && cs.db) {
+            const float t = (redc[0][cl] + redc[1][cl]) + (redc[2][cl] + redc[3][cl]);
+            cs.db[co] = cs.accumulate ? cs.db[co] + t : t;
+        }
+        return;
+    }
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int per_tap = cout * cin;
     float prod = 0.f;
@@ -515,33 +542,6 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = prod;
         __syncthreads();
         if (threadIdx.x == 0) dot_part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
-    }
-}
-
-// csum[b][co] = sum over the image's splits; db[co] = sum_b csum[b][co].
-// block = 64 co x 16 batch lanes; the 16 lanes' partial db sums meet in LDS.
-__global__ void __launch_bounds__(1024) csum_reduce_kernel(const float* __restrict__ csum_part, int B, int spi,
-                                                           int cout, int accumulate, float* __restrict__ csum,
-                                                           float* __restrict__ db) {
-    __shared__ float red[16][64];
-    const int cl = threadIdx.x & 63, bl = threadIdx.x >> 6;
-    const int co = blockIdx.x * 64 + cl;
-    float tot = 0.f;
-    if (co < cout) {
-        for (int b = bl; b < B; b += 16) {
-            float s = 0.f;
-            for (int k = 0; k < spi; ++k) s += csum_part[((size_t)b * spi + k) * cout + co];
-            if (csum) csum[(size_t)b * cout + co] = s;
-            tot += s;
-        }
-    }
-    red[bl][cl] = tot;
-    __syncthreads();
-    if (bl == 0 && co < cout && db) {
-        float t = 0.f;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) t += red[j][cl];
-        db[co] = accumulate ? db[co] + t : t;
     }
 }
 
@@ -663,14 +663,13 @@ static int wgrad_impl(const scm_conv3x3_wgrad_desc* d, int precision, void* stre
     const int dct = d->dw_cin_total ? d->dw_cin_total : cin;
     SCM_REQUIRE(d->dw_ci0 >= 0 && d->dw_ci0 + cin <= dct, "scm_conv3x3_wgrad: bad dw channel slice");
     SCM_REQUIRE(!d->dot_w || (d->dot_part && !(d->accumulate & 1)), "scm_conv3x3_wgrad: dot_w needs dot_part and no dw accumulation");
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, d->part_ws, p.nsplit, d->cout,
-                       cin, d->transposed_dst, d->accumulate & 1, dct, d->dw_ci0, d->dw, d->dot_w, d->dot_w ? d->dot_part : nullptr);
+    const int nblk_w = (total + 255) / 256;
+    CsumReduceArgs cs;
+    cs.csum_part = d->csum_ws; cs.B = d->B; cs.spi = p.spi; cs.accumulate = (d->accumulate >> 1) & 1; cs.csum = d->csum; cs.db = d->db;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nblk_w + (want_cs ? (d->cout + 63) / 64 : 0)), dim3(256), 0, s, d->part_ws,
+                       p.nsplit, d->cout, cin, d->transposed_dst, d->accumulate & 1, dct, d->dw_ci0, d->dw, d->dot_w,
+                       d->dot_w ? d->dot_part : nullptr, nblk_w, cs);
     SCM_LAUNCH_CHECK("wgrad_reduce_kernel");
-    if (want_cs) {
-        hipLaunchKernelGGL(csum_reduce_kernel, dim3((d->cout + 63) / 64), dim3(1024), 0, s, d->csum_ws, d->B, p.spi,
-                           d->cout, (d->accumulate >> 1) & 1, d->csum, d->db);
-        SCM_LAUNCH_CHECK("csum_reduce_kernel");
-    }
     return SCM_OK;
 }
 
