@@ -1,4 +1,4 @@
-"""smoke(): one small encoder -> decoder/loss -> transition step with backward
+"""smoke(): one small encoder -> fused decoder + loss -> transition step with backward
 on cuda:0 through the C ABI, checked against the CPU oracle."""
 import os
 import sys
@@ -31,7 +31,7 @@ def smoke():
     dec.load_state_dict(WS.to_torch(WS.decoder_state(2)))
     tr.set_noise([torch.from_numpy(noise).cuda()])
     z = enc(torch.from_numpy(frames).cuda())
-    loss = ops.pixel_bce(dec(z), torch.from_numpy(target).cuda()).mean()
+    loss = dec.forward_loss(z, torch.from_numpy(target).cuda()).mean()      # fused decoder + BCE (scm_decoder_fused_*)
     z2 = tr(z, torch.from_numpy(act).cuda())
     (loss + (z2 * 0.01).sum()).backward()
     # ---- oracle
