@@ -280,7 +280,7 @@ def main():
     ap.add_argument("--channels", type=int, default=3)
     ap.add_argument("--actions", type=int, default=5)
     ap.add_argument("--rewards", type=int, default=2)
-    ap.add_argument("--precision", choices=("fp32", "fp16"), default="fp32",
+    ap.add_argument("--precision", choices=("fp32", "fp32x3", "fp16"), default="fp32",
                     help="MFMA operand precision of the 3x3 convs. fp32 (default) is the reference's arithmetic and the "
                          "only valid headline; fp16 = opt-in fp16 forward / bf16 gradient operands with fp32 accumulation "
                          "(BASELINE configs[4]), reported as a separate, non-headline line")
@@ -356,7 +356,11 @@ def main():
             "metric": "predicted frames/sec/node (minipacman 64x64, horizon=10) + rollout L1 vs ref",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if a.precision == "fp32" else "f16 fwd / bf16 bwd MFMA operands, f32 accumulate + f32 tensors",
+            "dtype": {"fp32": "f32",
+                      "fp32x3": "f32 emulated on the bf16 MFMA pipe (operands split exactly into 3 bf16, 6 products per term, "
+                                "f32 accumulate; error vs float64 = the native f32 kernel's); weight gradients and thin layers "
+                                "native f32",
+                      "fp16": "f16 fwd / bf16 bwd MFMA operands, f32 accumulate + f32 tensors"}[a.precision],
             "data": "synthetic",
             "config": {"workload": "%s: %dx%dx%d frames, per-GPU batch %d, horizon %d, A=%d, R=%d, "
                                    "training iteration fwd+bwd+clip+Adam, reference loss (BCE + reward MSE), %s"
@@ -391,7 +395,7 @@ def main():
             # HBM bytes per launch: a PMC measurement (separate rocprofv3 --pmc passes, tools/prof_hot2.py) cited
             # from profiles/, valid only while the kernel's source is the one it was measured on (else null)
             tr_info = measured_traffic(name)
-            peak = PEAK_F32_MFMA_TFLOPS if "h16" not in name else PEAK_F16_MFMA_TFLOPS
+            peak = PEAK_F16_MFMA_TFLOPS if "h16" in name else (PEAK_F16_MFMA_TFLOPS / 6.0 if "x3" in name else PEAK_F32_MFMA_TFLOPS)
             out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": peak,
                                "unit": "TFLOP/s", "frac": achieved / peak,
                                "traffic": tr_info["bytes"] if tr_info else None, "traffic_source": tr_info,

@@ -39,6 +39,9 @@ extern "C" {
 #define SCM_PREC_F32 0
 #define SCM_PREC_F16 1
 #define SCM_PREC_BF16 2
+/* fp32 arithmetic on the bf16 MFMA pipe: operands split exactly into three bf16 values, six partial products per
+ * product, fp32 accumulation (scm_conv3x3_x3 / scm_conv3x3_wgrad_x3): fp32-grade results, not a 16-bit mode */
+#define SCM_PREC_BF16X3 3
 
 #define SCM_ACT_NONE 0
 #define SCM_ACT_LRELU 1     /* F.leaky_relu(x), slope 0.01: models.py:77,146,... */
@@ -319,6 +322,20 @@ typedef struct scm_csrn_desc {
 int scm_csrn_sweep_fwd(const scm_csrn_desc* d, void* stream);
 int scm_csrn_sweep_bwd(const scm_csrn_desc* d, const float* dctx, float* dx, float* slab, float* dparams,
                        void* stream);
+
+/* ------------------------------------------------------------------------
+ * fp32 convolution emulated on the bf16 MFMA pipe (opt-in, csrc/conv3x3_x3.hip).  Same descriptor, tensors (fp32
+ * NCHW), epilogue and gate handling as scm_conv3x3; every fp32 operand is split EXACTLY into hi + mid + lo bf16 values
+ * and each product is the sum of the six partial products of order <= 2 (error <= 2^-23 of the product, i.e. one fp32
+ * rounding), accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  Frames whose 512-pixel halo tile exceeds 768 elements
+ * (wider than ~64) return SCM_EUNSUPPORTED: callers keep scm_conv3x3 there.
+ *   pack: scm_conv3x3_pack_x3_bytes(cin, cout) bytes, built by scm_pack_conv3x3_weights_x3 (arguments as
+ *         scm_pack_conv3x3_weights).
+ * ---------------------------------------------------------------------- */
+size_t scm_conv3x3_pack_x3_bytes(int cin, int cout);
+int scm_pack_conv3x3_weights_x3(const float* w, int cin, int cout, int transposed_src, int w_cin_total, int w_ci0,
+                                void* fwd_pack, void* dgrad_pack, void* stream);
+int scm_conv3x3_x3(const scm_conv3x3_desc* d, void* stream);
 
 /* ------------------------------------------------------------------------
  * Fused decoder + pixel loss: one pass over the latent (SURVEY.md 8(b) scm_decoder_fused_*).

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libscmgan_hip.so")
 
 PAD_ZERO, PAD_CIRCULAR = 0, 1
 ACT_NONE, ACT_LRELU, ACT_SIGMOID = 0, 1, 2
-PREC_F32, PREC_F16, PREC_BF16 = 0, 1, 2
+PREC_F32, PREC_F16, PREC_BF16, PREC_BF16X3 = 0, 1, 2, 3
 
 c_float_p = ctypes.c_void_p  # raw device pointers travel as void*
 
@@ -145,6 +145,9 @@ def lib():
             "scm_csrn_sweep_fwd": [vp, vp],
             "scm_csrn_sweep_bwd": [vp, vp, vp, vp, vp, vp],
             "scm_adam_clip_multi": [ci, vp, vp, vp, vp, vp, cf, cf, cf, cf, ci, vp, cf, cf, vp],
+            "scm_conv3x3_pack_x3_bytes": [ci, ci],
+            "scm_pack_conv3x3_weights_x3": [vp, ci, ci, ci, ci, ci, vp, vp, vp],
+            "scm_conv3x3_x3": [vp, vp],
             "scm_decoder_fused_pack_floats": [],
             "scm_decoder_fused_pack": [vp, vp, vp, vp, ci, ci, vp, vp],
             "scm_decoder_fused_workspace": [ci, ci, ci, ci, vp, vp],
@@ -160,7 +163,7 @@ def lib():
             fn = getattr(L, name)      # raises AttributeError when the library lacks a declared symbol
             fn.argtypes = args
             fn.restype = ctypes.c_size_t if name in ("scm_conv3x3_pack_floats", "scm_conv2d_bwd_workspace",
-                                                  "scm_conv3x3_pack_h16_bytes", "scm_decoder_fused_pack_floats",
+                                                  "scm_conv3x3_pack_h16_bytes", "scm_conv3x3_pack_x3_bytes", "scm_decoder_fused_pack_floats",
                                                   "scm_reward_fused_pack_floats") \
                 else ctypes.c_int
         L._scm_symbols = sorted(sigs) + ["scm_version", "scm_last_error"]

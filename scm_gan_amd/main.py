@@ -54,7 +54,7 @@ parser.add_argument('--enable-disentanglement-loss', action='store_true', help='
 parser.add_argument('--counterfactual-horizon', type=int, default=1, help='Forward horizon for CF generation')
 # additions of this build
 parser.add_argument('--seed', type=int, default=0, help='Seed of weights, data and the Philox latent noise')
-parser.add_argument('--precision', choices=('fp32', 'fp16'), default='fp32',
+parser.add_argument('--precision', choices=('fp32', 'fp32x3', 'fp16'), default='fp32',
                     help="MFMA operand precision of the 3x3 convs: fp32 = the reference's arithmetic; fp16 = fp16 forward / "
                          "bf16 gradient operands with fp32 accumulation (not in the reference)")
 parser.add_argument('--prefetch', type=int, default=0,

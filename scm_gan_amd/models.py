@@ -149,7 +149,7 @@ class RewardPredictor(nn.Module):
 
     def _fused(self, x):
         return x.shape[1] == 16 and self.num_rewards <= 2 and 5 <= x.shape[3] <= 64 and x.shape[2] >= 5 and \
-            ops.compute_precision() == "fp32" and os.environ.get("SCM_NO_FUSED_REWARD", "0") in ("", "0")
+            ops.compute_precision() != "fp16" and os.environ.get("SCM_NO_FUSED_REWARD", "0") in ("", "0")
 
     def _fused_pack(self):
         ps = (self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias)
@@ -192,7 +192,7 @@ class Decoder(nn.Module):
     # ---- fused path (scm_decoder_fused_*): one pass over z, the 64-channel hidden map stays on chip.
     # Serves latent_size 16 and <= 3 colour channels in the fp32 mode; anything else takes the layer-by-layer path.
     def _fused(self):
-        return self.latent_size == 16 and self.color_channels <= 3 and ops.compute_precision() == "fp32" \
+        return self.latent_size == 16 and self.color_channels <= 3 and ops.compute_precision() != "fp16" \
             and os.environ.get("SCM_NO_FUSED_DECODER", "0") in ("", "0")
 
     def _fused_pack(self):

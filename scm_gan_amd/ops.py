@@ -66,8 +66,14 @@ def _stream():
 # bf16 operands, both with fp32 accumulation over the same fp32 tensors
 # (scm_conv3x3_h16; BASELINE config 5 / SURVEY.md 8(d)).  Opt-in: parity claims and the
 # headline benchmark are fp32.
-PREC_F32, PREC_F16, PREC_BF16 = L.PREC_F32, L.PREC_F16, L.PREC_BF16
-_precision = ["fp32"]
+#
+# "fp32x3": fp32 arithmetic on the bf16 MFMA pipe (scm_conv3x3_x3): every operand split exactly into three bf16
+# values, six partial products per product, fp32 accumulation.  fp32-grade results (tests/test_gpu_x3_mode.py
+# measures its error against float64 next to the native kernel's) at 6/16 of the f32 MFMA cost.  Serves the forward
+# and input-gradient convolutions with more than 16 output channels on frames up to 64 wide; everything else
+# (weight gradients, thin layers, fused decoder / reward head) runs the native fp32 kernels in this mode too.
+PREC_F32, PREC_F16, PREC_BF16, PREC_BF16X3 = L.PREC_F32, L.PREC_F16, L.PREC_BF16, L.PREC_BF16X3
+_precision = [os.environ.get("SCM_PRECISION", "fp32") or "fp32"]      # (the environment default lets the whole fp32 parity suite run in another mode)
 
 
 def compute_precision():
@@ -75,8 +81,8 @@ def compute_precision():
 
 
 def set_compute_precision(name):
-    if name not in ("fp32", "fp16"):
-        raise ValueError("compute precision must be 'fp32' or 'fp16', got %r" % (name,))
+    if name not in ("fp32", "fp16", "fp32x3"):
+        raise ValueError("compute precision must be 'fp32', 'fp32x3' or 'fp16', got %r" % (name,))
     _precision[0] = name
 
 
@@ -96,7 +102,26 @@ def pack_conv3x3(weight, cin, cout, transposed=False, cin_total=0, ci0=0):
     dp = _new(w, lib.scm_conv3x3_pack_floats(cout, cin))
     L.check(lib.scm_pack_conv3x3_weights(_p(w), cin, cout, int(transposed), cin_total, ci0, _p(fp), _p(dp), _stream()),
             "scm_pack_conv3x3_weights")
+    if _precision[0] == "fp32x3":
+        # split packs for the directions the x3 kernel serves (> 16 output channels); the native packs stay as the
+        # per-call fallback for frames it does not take (x3_serves)
+        fx = dx = None
+        if cout > 16:
+            fx = torch.empty(lib.scm_conv3x3_pack_x3_bytes(cin, cout) // 2, device=w.device, dtype=torch.int16)
+        if cin > 16:
+            dx = torch.empty(lib.scm_conv3x3_pack_x3_bytes(cout, cin) // 2, device=w.device, dtype=torch.int16)
+        if fx is not None or dx is not None:
+            L.check(lib.scm_pack_conv3x3_weights_x3(_p(w), cin, cout, int(transposed), cin_total, ci0, _p(fx), _p(dx),
+                                                    _stream()), "scm_pack_conv3x3_weights_x3")
+        return (fx if fx is not None else fp, dx if dx is not None else dp, PREC_BF16X3 if fx is not None else PREC_F32,
+                PREC_BF16X3 if dx is not None else PREC_F32, fp, dp)
     return fp, dp, PREC_F32, PREC_F32
+
+
+def x3_serves(H, W):
+    """scm_conv3x3_x3 stages the halo tile of 512 pixels in 768 slots per channel."""
+    rows = 512 // W if 512 % W == 0 else (512 + W - 2) // W + 1
+    return (min(rows, H) + 2) * (W + 2) <= 768
 
 
 class KernelTimer(object):
@@ -126,6 +151,8 @@ kernel_timer = None     # set to a KernelTimer() to time the MFMA conv launches
 
 
 def conv_kernel_name(cout, prec=0):
+    if prec == PREC_BF16X3:
+        return "conv3x3_x3_kernel"
     if prec:
         return "conv3x3_h16_kernel<%s>" % ("f16" if prec == PREC_F16 else "bf16")
     if cout <= 16:
@@ -153,7 +180,9 @@ def _conv3x3_raw(x1, x2, gate1, gate2, gate_act, wpack, cout, scale, bias, sbias
     if kernel_timer is not None:
         ev = kernel_timer.bracket(conv_kernel_name(cout, prec), 2.0 * B * H * W * cout * (c1 + c2) * 9)
         ev[0].record()
-    if prec:
+    if prec == PREC_BF16X3:
+        L.check(lib.scm_conv3x3_x3(ctypes.byref(d), _stream()), "scm_conv3x3_x3")
+    elif prec:
         L.check(lib.scm_conv3x3_h16(ctypes.byref(d), prec, _stream()), "scm_conv3x3_h16")
     else:
         L.check(lib.scm_conv3x3(ctypes.byref(d), _stream()), "scm_conv3x3")
@@ -255,7 +284,9 @@ class Conv3x3Fn(Function):
         c2 = 0 if x2 is None else x2.shape[1]
         cout = w.shape[1] if cfg["transposed"] else w.shape[0]
         cin_total = w.shape[0] if cfg["transposed"] else w.shape[1]
-        fpack, dpack, fprec, dprec = cfg["packs"]
+        fpack, dpack, fprec, dprec = cfg["packs"][:4]
+        if (fprec == PREC_BF16X3 or dprec == PREC_BF16X3) and not x3_serves(H, W):
+            fpack, dpack, fprec, dprec = cfg["packs"][4], cfg["packs"][5], PREC_F32, PREC_F32
         sbias = None
         if act_vec is not None:
             A = act_vec.shape[1]
@@ -324,7 +355,7 @@ class Conv3x3Fn(Function):
             d = L.WgradDesc(_p(x1), _p(x2), c1, c2, _p(gy), _p(y) if act else None, act, cout, _p(dw_eff), _p(db),
                             _p(csum), _p(part), _p(cws), B, H, W, cfg["pad"], int(cfg["transposed"]), acc_flag,
                             cin_total, 0, _p(w) if dot_part is not None else None, _p(dot_part), _p(ctx.mask))
-            if ctx.dprec:
+            if ctx.dprec in (PREC_F16, PREC_BF16):
                 L.check(lib.scm_conv3x3_wgrad_h16(ctypes.byref(d), ctx.dprec, _stream()), "scm_conv3x3_wgrad_h16")
             else:
                 L.check(lib.scm_conv3x3_wgrad(ctypes.byref(d), _stream()), "scm_conv3x3_wgrad")
