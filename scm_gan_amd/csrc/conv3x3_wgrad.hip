@@ -631,7 +631,10 @@ static int wgrad_impl(const scm_conv3x3_wgrad_desc* d, int precision, void* stre
     a.gate_mask = d->gate_mask;
     hipStream_t s = (hipStream_t)stream;
     int rc;
-    if (precision != SCM_PREC_F32 && d->cout > 64 && p.m16 == 0 && p.mt == 4) {
+    if (precision == SCM_PREC_BF16X3 && d->cout > 64 && p.m16 == 0 && p.mt == 4) {
+        // fp32 arithmetic on the bf16 MFMA pipe (conv3x3_wgrad_x3.hip); same split, same slabs
+        rc = scm_launch_wgrad_x3(a, p, s);
+    } else if (precision != SCM_PREC_F32 && precision != SCM_PREC_BF16X3 && d->cout > 64 && p.m16 == 0 && p.mt == 4) {
         // 128 co x 64 (32) ci tiles on the 16-bit MFMA (conv3x3_wgrad_h16.hip); same split, same slabs.
         // cin <= 16 (Transition.conv1) stays on the fp32 kernel: that launch is bound by reading dy,
         // 16-bit operands gain nothing there (106 vs 109 us) and cost gradient accuracy.
@@ -680,7 +683,7 @@ extern "C" int scm_conv3x3_wgrad(const scm_conv3x3_wgrad_desc* d, void* stream) 
 // Opt-in: the 128 co x 64 ci workgroup tiles run on bf16/fp16 operands (fp32 accumulate, fp32
 // partial slabs and reduction); every other shape uses the fp32 kernels above.
 extern "C" int scm_conv3x3_wgrad_h16(const scm_conv3x3_wgrad_desc* d, int precision, void* stream) {
-    SCM_REQUIRE(precision == SCM_PREC_F16 || precision == SCM_PREC_BF16, "scm_conv3x3_wgrad_h16: bad precision %d",
-                precision);
+    SCM_REQUIRE(precision == SCM_PREC_F16 || precision == SCM_PREC_BF16 || precision == SCM_PREC_BF16X3,
+                "scm_conv3x3_wgrad_h16: bad precision %d", precision);
     return wgrad_impl(d, precision, stream);
 }

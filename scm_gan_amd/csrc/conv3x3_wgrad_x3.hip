@@ -1,0 +1,330 @@
+// Weight gradient of the 3x3 same-size convolution in fp32 arithmetic on the bf16 MFMA pipe: the companion of
+// conv3x3_x3.hip (which explains the exact three-way bf16 split and the six partial products per product).
+//
+//   dWc[co][ci][tap] = sum_{b,p} dyp[b,co,p] * Xpad[b,ci,p+tap],  dyp = dy * act'(y)
+//
+// Same work split, fp32 partial slabs part[split][tap][co][ci], fixed-order reduction and per-sample channel sums
+// as conv3x3_wgrad.hip / conv3x3_wgrad_h16.hip.  GEMM view as in the 16-bit kernel: M = co, N = ci, K = 8
+// consecutive pixels per lane fragment, one accumulator per tap.  Differences from the 16-bit kernel:
+//   * both operands are staged as three LDS images (hi / mid / lo), split while staging;
+//   * the x row is stored ONCE (plus a halo unit on each side), not as three pre-shifted images -- three components
+//     of three shifted images would not fit the LDS; the kx = 0 / 2 fragments are built in registers from the unit and
+//     its neighbours with five v_alignbit_b32 per (row, component);
+//   * 128 co x 32 ci per workgroup, 4 waves (one per SIMD, the 9 tap accumulators in AGPRs), dy single-buffered.
+#include "wgrad_args.h"
+
+typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
+typedef __bf16 b16x8w __attribute__((ext_vector_type(8)));
+typedef __bf16 b16x2w __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x16 wmfma_bf16(u32x4w a, u32x4w b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b16x8w, a), __builtin_bit_cast(b16x8w, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ void wsplit3_pair(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
+    b16x2w h = {(__bf16)x0, (__bf16)x1};
+    const float r0 = x0 - (float)h[0], r1 = x1 - (float)h[1];
+    b16x2w m = {(__bf16)r0, (__bf16)r1};
+    const float s0 = r0 - (float)m[0], s1 = r1 - (float)m[1];
+    b16x2w l = {(__bf16)s0, (__bf16)s1};
+    hi = __builtin_bit_cast(unsigned, h);
+    mid = __builtin_bit_cast(unsigned, m);
+    lo = __builtin_bit_cast(unsigned, l);
+}
+
+#define X3W_NG 8                       // 8-pixel groups per row segment (PS <= 64)
+#define X3W_XP 33                      // ci pitch of an x image (units)
+#define X3W_XG (X3W_NG + 2)            // groups incl. one halo unit on each side
+#define X3W_XCOMP (X3W_XG * X3W_XP)    // units per component of an x row slot
+#define X3W_XSLOT (3 * X3W_XCOMP)
+#define X3W_DP 129                     // co pitch of the dyp image
+#define X3W_DCOMP (X3W_NG * X3W_DP)
+
+template <bool VEC>
+__global__ void __launch_bounds__(256, 1) conv3x3_wgrad_x3_kernel(const WgradKArgs a) {
+    extern __shared__ __attribute__((aligned(16))) u32x4w wsx[];
+    u32x4w* xs = wsx;                          // [4 slots][3 comps][X3W_XG][X3W_XP]
+    u32x4w* dsm = wsx + 4 * X3W_XSLOT;         // [3 comps][X3W_NG][X3W_DP]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wm = wave;                       // co tile of this wave
+    const int W = a.W, H = a.H, HW = H * W;
+    const int PS = a.PS;
+
+    // grid: x = ci group (fastest: the groups of one split run side by side and share its dy rows in L2), y = split
+    const int cig = blockIdx.x % a.ci_groups;
+    const int cog = blockIdx.x / a.ci_groups;
+    const int split = blockIdx.y;
+    const int b = split / a.spi;
+    const int si = split - b * a.spi;
+    const int y_begin = si * a.rows_per_split;
+    int y_end = y_begin + a.rows_per_split;
+    if (y_end > H) y_end = H;
+    const int co_base = cog * 128, ci_base = cig * 32;
+    const int cin = a.c1 + a.c2;
+    const bool circ = a.pad_mode == SCM_PAD_CIRCULAR;
+    const int gate_act = a.gate_act;
+    const bool gated = gate_act != 0;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // ---- staging roles (as the 4-wave form of the 16-bit kernel)
+    const int xc = tid >> 3, xg = tid & 7;
+    const int xci = ci_base + xc;
+    const bool xvalid = xci < cin;
+    const int xcc = xvalid ? xci : 0;
+    const float* xsrc = xcc < a.c1 ? a.x1 + ((size_t)b * a.c1 + xcc) * HW : a.x2 + ((size_t)b * a.c2 + (xcc - a.c1)) * HW;
+    constexpr int DT = 4, DSTEP = 32;
+    const int dg = tid & 7;
+    const float* dsrc[DT];
+    const float* gsrc[DT];
+    bool dvalid[DT];
+    int dbit[DT];
+    const bool use_mask = a.gate_mask != nullptr && gate_act == SCM_ACT_LRELU;
+    const int mask_nw = (a.cout + 31) >> 5;
+#pragma unroll
+    for (int j = 0; j < DT; ++j) {
+        const int co = co_base + (tid >> 3) + DSTEP * j;
+        dvalid[j] = co < a.cout;
+        const size_t o = ((size_t)b * a.cout + (dvalid[j] ? co : 0)) * HW;
+        dsrc[j] = a.dy + o;
+        gsrc[j] = (gated ? a.gate : a.dy) + o;
+        dbit[j] = co & 31;
+        if (use_mask) {
+            const int w = (dvalid[j] ? co : 0) >> 5;
+            gsrc[j] = reinterpret_cast<const float*>(a.gate_mask + ((size_t)b * mask_nw + w) * HW);
+        }
+    }
+    float csum[DT];
+#pragma unroll
+    for (int j = 0; j < DT; ++j) csum[j] = 0.f;
+    const bool do_csum = a.csum_part != nullptr && cig == 0;
+
+    float px[10];
+    float pd[DT][8], pgv[DT][8];
+
+    for (int seg = 0; seg < a.nseg; ++seg) {
+        const int x0 = seg * PS;
+        int ps = W - x0;
+        if (ps > PS) ps = PS;
+        const int nks = (ps + 15) >> 4;
+
+        auto load8 = [&](const float* row, int c0, float* v) {
+            if constexpr (VEC) {
+                const int cc = c0 + 7 < W ? c0 : W - 8;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(row + cc);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(row + cc + 4);
+                v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+                v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int c = c0 + i;
+                    v[i] = row[c < W ? c : W - 1];
+                }
+            }
+        };
+        const int xc0 = x0 + 8 * xg;
+        const int dc0 = x0 + 8 * dg;
+
+        auto fetch_x = [&](int r) {
+            int ri = r;
+            if (circ) ri = r < 0 ? r + H : (r >= H ? r - H : r);
+            ri = ri < 0 ? 0 : (ri >= H ? H - 1 : ri);
+            const float* row = xsrc + (size_t)ri * W;
+            load8(row, xc0, px + 1);
+            int cl = xc0 - 1, cr = xc0 + 8;
+            if (circ) {
+                cl = cl < 0 ? cl + W : cl;
+                cr = cr >= W ? cr - W : cr;
+            }
+            cl = cl < 0 ? 0 : (cl >= W ? W - 1 : cl);
+            cr = cr >= W ? W - 1 : cr;
+            px[0] = row[cl];
+            px[9] = row[cr];
+        };
+        auto store_x = [&](int r) {
+            bool rok = xvalid;
+            if (!circ) rok = rok && r >= 0 && r < H;
+            float v[10];
+#pragma unroll
+            for (int i = 0; i < 10; ++i) {
+                const int c = xc0 - 1 + i;
+                const bool ok = rok && (circ || (c >= 0 && c < W)) && (c < x0 + ps + 1);
+                v[i] = ok ? px[i] : 0.f;
+            }
+            unsigned hh[5], mm[5], ll[5];           // pairs (v0,v1) (v2.. no: (v1,v2),(v3,v4),(v5,v6),(v7,v8) + halo pair (v0,v9)
+            wsplit3_pair(v[1], v[2], hh[0], mm[0], ll[0]);
+            wsplit3_pair(v[3], v[4], hh[1], mm[1], ll[1]);
+            wsplit3_pair(v[5], v[6], hh[2], mm[2], ll[2]);
+            wsplit3_pair(v[7], v[8], hh[3], mm[3], ll[3]);
+            wsplit3_pair(v[9], v[0], hh[4], mm[4], ll[4]);      // low half = p0+8 (right halo), high half = p0-1 (left halo)
+            u32x4w* slot = xs + ((r + 1) & 3) * X3W_XSLOT + (xg + 1) * X3W_XP + xc;
+            u32x4w u;
+            u[0] = hh[0]; u[1] = hh[1]; u[2] = hh[2]; u[3] = hh[3];
+            slot[0] = u;
+            u[0] = mm[0]; u[1] = mm[1]; u[2] = mm[2]; u[3] = mm[3];
+            slot[X3W_XCOMP] = u;
+            u[0] = ll[0]; u[1] = ll[1]; u[2] = ll[2]; u[3] = ll[3];
+            slot[2 * X3W_XCOMP] = u;
+            if (xg == 0) {                              // left halo unit: element 7 = pixel x0 - 1
+                u32x4w* hs = slot - X3W_XP;
+                u[0] = 0u; u[1] = 0u; u[2] = 0u;
+                u[3] = hh[4] & 0xffff0000u; hs[0] = u;
+                u[3] = mm[4] & 0xffff0000u; hs[X3W_XCOMP] = u;
+                u[3] = ll[4] & 0xffff0000u; hs[2 * X3W_XCOMP] = u;
+            }
+            if (xg == X3W_NG - 1) {                     // right halo unit: element 0 = pixel x0 + 64
+                u32x4w* hs = slot + X3W_XP;
+                u[1] = 0u; u[2] = 0u; u[3] = 0u;
+                u[0] = hh[4] & 0xffffu; hs[0] = u;
+                u[0] = mm[4] & 0xffffu; hs[X3W_XCOMP] = u;
+                u[0] = ll[4] & 0xffffu; hs[2 * X3W_XCOMP] = u;
+            }
+        };
+        auto fetch_d = [&](int y) {
+#pragma unroll
+            for (int j = 0; j < DT; ++j) {
+                load8(dsrc[j] + (size_t)y * W, dc0, pd[j]);
+                load8(gsrc[j] + (size_t)y * W, dc0, pgv[j]);
+            }
+        };
+        auto store_d = [&]() {
+#pragma unroll
+            for (int j = 0; j < DT; ++j) {
+                float v[8];
+                float s = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int c = dc0 + i;
+                    float t = pd[j][i];
+                    if (use_mask) t *= ((__float_as_uint(pgv[j][i]) >> dbit[j]) & 1u) ? 1.f : 0.01f;
+                    else if (gated) t *= scm_act_grad_from_out(pgv[j][i], gate_act);
+                    v[i] = (dvalid[j] && c < x0 + ps) ? t : 0.f;
+                    s += v[i];
+                }
+                csum[j] += s;
+                u32x4w uh, um, ul;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    unsigned hi, mid, lo;
+                    wsplit3_pair(v[2 * q], v[2 * q + 1], hi, mid, lo);
+                    uh[q] = hi; um[q] = mid; ul[q] = lo;
+                }
+                u32x4w* dd = dsm + dg * X3W_DP + (tid >> 3) + DSTEP * j;
+                dd[0] = uh;
+                dd[X3W_DCOMP] = um;
+                dd[2 * X3W_DCOMP] = ul;
+            }
+        };
+
+        __syncthreads();                         // the previous segment's MFMAs are done with the images
+        fetch_x(y_begin - 1);
+        store_x(y_begin - 1);
+        fetch_x(y_begin);
+        store_x(y_begin);
+        fetch_x(y_begin + 1);
+        fetch_d(y_begin);
+
+        for (int y = y_begin; y < y_end; ++y) {
+            store_x(y + 1);
+            store_d();
+            __syncthreads();
+            if (y + 1 < y_end) {
+                fetch_x(y + 2);
+                fetch_d(y + 1);
+            }
+            const u32x4w* dst = dsm + wm * 32 + l31;
+            for (int ks = 0; ks < nks; ++ks) {
+                const int g = 2 * ks + lh;
+                u32x4w av[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) av[c] = dst[c * X3W_DCOMP + g * X3W_DP];
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const u32x4w* xr = xs + ((y + ky) & 3) * X3W_XSLOT + (g + 1) * X3W_XP + l31;
+                    u32x4w f0[3], f1[3], f2[3];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const u32x4w u = xr[c * X3W_XCOMP];
+                        const unsigned pw = reinterpret_cast<const unsigned*>(xr + c * X3W_XCOMP - X3W_XP)[3];   // previous unit, pixels 6..7
+                        const unsigned nx = reinterpret_cast<const unsigned*>(xr + c * X3W_XCOMP + X3W_XP)[0];   // next unit, pixels 0..1
+                        const unsigned s01 = __builtin_amdgcn_alignbit(u[1], u[0], 16);
+                        const unsigned s12 = __builtin_amdgcn_alignbit(u[2], u[1], 16);
+                        const unsigned s23 = __builtin_amdgcn_alignbit(u[3], u[2], 16);
+                        f1[c] = u;
+                        f0[c][0] = __builtin_amdgcn_alignbit(u[0], pw, 16);       // pixels p-1 .. p+6
+                        f0[c][1] = s01; f0[c][2] = s12; f0[c][3] = s23;
+                        f2[c][0] = s01; f2[c][1] = s12; f2[c][2] = s23;           // pixels p+1 .. p+8
+                        f2[c][3] = __builtin_amdgcn_alignbit(nx, u[3], 16);
+                    }
+                    auto six = [&](f32x16 c, const u32x4w* f) {
+                        c = wmfma_bf16(av[2], f[0], c);
+                        c = wmfma_bf16(av[0], f[2], c);
+                        c = wmfma_bf16(av[1], f[1], c);
+                        c = wmfma_bf16(av[1], f[0], c);
+                        c = wmfma_bf16(av[0], f[1], c);
+                        c = wmfma_bf16(av[0], f[0], c);
+                        return c;
+                    };
+                    acc[ky * 3 + 0] = six(acc[ky * 3 + 0], f0);
+                    acc[ky * 3 + 1] = six(acc[ky * 3 + 1], f1);
+                    acc[ky * 3 + 2] = six(acc[ky * 3 + 2], f2);
+                }
+            }
+            __syncthreads();                     // dyp image (single stage) free for the next row
+        }
+    }
+
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co_base + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int ci = ci_base + l31;
+            if (co < a.cout && ci < cin) a.part[(((size_t)split * 9 + t) * a.cout + co) * cin + ci] = acc[t][r];
+        }
+    }
+    if (do_csum) {
+#pragma unroll
+        for (int j = 0; j < DT; ++j) {
+            float s = csum[j];
+            s += __shfl_xor(s, 1);
+            s += __shfl_xor(s, 2);
+            s += __shfl_xor(s, 4);
+            const int co = co_base + (tid >> 3) + DSTEP * j;
+            if (dg == 0 && co < a.cout) a.csum_part[(size_t)split * a.cout + co] = s;
+        }
+    }
+}
+
+int scm_launch_wgrad_x3(const WgradKArgs& k, const WgradPlan& p, hipStream_t s) {
+    if (k.PS > 64 || k.W < 8) {
+        scm_set_error("scm_conv3x3_wgrad_x3: row segment of %d pixels (W = %d) unsupported", k.PS, k.W);
+        return SCM_EUNSUPPORTED;
+    }
+    WgradKArgs a = k;
+    const int cin = a.c1 + a.c2;
+    a.ci_groups = (cin + 31) / 32;
+    const bool vec = (a.W % 4 == 0) && (a.PS % 8 == 0) &&
+                     ((reinterpret_cast<size_t>(a.x1) | reinterpret_cast<size_t>(a.x2) | reinterpret_cast<size_t>(a.dy) |
+                       reinterpret_cast<size_t>(a.gate) | reinterpret_cast<size_t>(a.gate_mask)) % 16 == 0);
+    const size_t lds = ((size_t)4 * X3W_XSLOT + 3 * X3W_DCOMP) * 16;
+    const dim3 grid(p.co_groups * a.ci_groups, p.nsplit);
+    static std::atomic<uint64_t> attr_done[2];
+    if (vec) {
+        if (int rc = scm_ensure_lds_attr(reinterpret_cast<const void*>(conv3x3_wgrad_x3_kernel<true>), attr_done[0], 160 * 1024)) return rc;
+        hipLaunchKernelGGL(conv3x3_wgrad_x3_kernel<true>, grid, dim3(256), lds, s, a);
+    } else {
+        if (int rc = scm_ensure_lds_attr(reinterpret_cast<const void*>(conv3x3_wgrad_x3_kernel<false>), attr_done[1], 160 * 1024)) return rc;
+        hipLaunchKernelGGL(conv3x3_wgrad_x3_kernel<false>, grid, dim3(256), lds, s, a);
+    }
+    SCM_LAUNCH_CHECK("conv3x3_wgrad_x3_kernel");
+    return SCM_OK;
+}

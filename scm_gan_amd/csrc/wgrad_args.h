@@ -19,3 +19,6 @@ struct WgradPlan {
 
 // 128 co x 64 ci tiles on v_mfma_f32_32x32x16_{f16,bf16} (conv3x3_wgrad_h16.hip)
 int scm_launch_wgrad_h16(const WgradKArgs& a, const WgradPlan& p, int precision, hipStream_t s);
+
+// fp32 arithmetic on the bf16 MFMA pipe, 128 co x 32 ci tiles (conv3x3_wgrad_x3.hip)
+int scm_launch_wgrad_x3(const WgradKArgs& a, const WgradPlan& p, hipStream_t s);

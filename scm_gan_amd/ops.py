@@ -355,8 +355,12 @@ class Conv3x3Fn(Function):
             d = L.WgradDesc(_p(x1), _p(x2), c1, c2, _p(gy), _p(y) if act else None, act, cout, _p(dw_eff), _p(db),
                             _p(csum), _p(part), _p(cws), B, H, W, cfg["pad"], int(cfg["transposed"]), acc_flag,
                             cin_total, 0, _p(w) if dot_part is not None else None, _p(dot_part), _p(ctx.mask))
-            if ctx.dprec in (PREC_F16, PREC_BF16):
-                L.check(lib.scm_conv3x3_wgrad_h16(ctypes.byref(d), ctx.dprec, _stream()), "scm_conv3x3_wgrad_h16")
+            wprec = ctx.dprec
+            if compute_precision() == "fp32x3":
+                # the split kernel takes 128-wide weight gradients of layers with more than 16 input channels
+                wprec = PREC_BF16X3 if (W >= 8 and x3_serves(H, W) and cout > 64 and c1 + c2 > 16) else PREC_F32
+            if wprec:
+                L.check(lib.scm_conv3x3_wgrad_h16(ctypes.byref(d), wprec, _stream()), "scm_conv3x3_wgrad_h16")
             else:
                 L.check(lib.scm_conv3x3_wgrad(ctypes.byref(d), _stream()), "scm_conv3x3_wgrad")
             if has_act:
