@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(256 * WN, 1) conv3x3_wgrad_h16_kernel(const Wg
     for (int j = 0; j < DT; ++j) csum[j] = 0.f;
     const bool do_csum = a.csum_part != nullptr && cig == 0;
 
-    float px[10];                 // pixels p0-1 .. p0+8 of the x row
+    float px[10], pe = 0.f;       // pixels p0-1 .. p0+8 of the x row; the pixel one past the segment
     float pd[DT][8], pgv[DT][8];
 
     for (int seg = 0; seg < a.nseg; ++seg) {
@@ -171,6 +171,11 @@ __global__ void __launch_bounds__(256 * WN, 1) conv3x3_wgrad_h16_kernel(const Wg
             cr = cr >= W ? W - 1 : cr;
             px[0] = row[cl];
             px[9] = row[cr];
+            // the pixel one past the segment (the kx = 2 tap of its last pixel): wherever it falls in this thread's
+            // ten, it is the wrapped column under circular padding -- load8 clamps instead of wrapping
+            int ce = x0 + ps;
+            if (circ) ce = ce >= W ? ce - W : ce;
+            pe = row[ce < W ? ce : W - 1];
         };
         auto store_x = [&](int r) {
             bool rok = xvalid;
@@ -180,7 +185,7 @@ __global__ void __launch_bounds__(256 * WN, 1) conv3x3_wgrad_h16_kernel(const Wg
             for (int i = 0; i < 10; ++i) {
                 const int c = xc0 - 1 + i;        // image column (before wrapping)
                 const bool ok = rok && (circ || (c >= 0 && c < W)) && (c < x0 + ps + 1);
-                v[i] = ok ? px[i] : 0.f;
+                v[i] = ok ? (c == x0 + ps ? pe : px[i]) : 0.f;
             }
             u32x4* slot = xs + ((r + 1) & 3) * WG_XSLOT + xg * WG_XP + xc;
             const unsigned m12 = wpack2<PREC>(v[1], v[2]), m34 = wpack2<PREC>(v[3], v[4]);

@@ -106,7 +106,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wgrad_x3_kernel(const WgradKAr
     for (int j = 0; j < DT; ++j) csum[j] = 0.f;
     const bool do_csum = a.csum_part != nullptr && cig == 0;
 
-    float px[10];
+    float px[10], pe = 0.f;
     float pd[DT][8], pgv[DT][8];
 
     for (int seg = 0; seg < a.nseg; ++seg) {
@@ -148,6 +148,11 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wgrad_x3_kernel(const WgradKAr
             cr = cr >= W ? W - 1 : cr;
             px[0] = row[cl];
             px[9] = row[cr];
+            // the pixel one past the segment (the kx = 2 tap of its last pixel): wherever it falls in this thread's
+            // ten, it is the wrapped column under circular padding -- load8 clamps instead of wrapping
+            int ce = x0 + ps;
+            if (circ) ce = ce >= W ? ce - W : ce;
+            pe = row[ce < W ? ce : W - 1];
         };
         auto store_x = [&](int r) {
             bool rok = xvalid;
@@ -157,7 +162,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wgrad_x3_kernel(const WgradKAr
             for (int i = 0; i < 10; ++i) {
                 const int c = xc0 - 1 + i;
                 const bool ok = rok && (circ || (c >= 0 && c < W)) && (c < x0 + ps + 1);
-                v[i] = ok ? px[i] : 0.f;
+                v[i] = ok ? (c == x0 + ps ? pe : px[i]) : 0.f;
             }
             unsigned hh[5], mm[5], ll[5];           // pairs (v0,v1) (v2.. no: (v1,v2),(v3,v4),(v5,v6),(v7,v8) + halo pair (v0,v9)
             wsplit3_pair(v[1], v[2], hh[0], mm[0], ll[0]);

@@ -105,10 +105,13 @@ def pack_conv3x3(weight, cin, cout, transposed=False, cin_total=0, ci0=0):
     if _precision[0] == "fp32x3":
         # split packs for the directions the x3 kernel serves (> 16 output channels); the native packs stay as the
         # per-call fallback for frames it does not take (x3_serves)
+        # measured per direction: the split forward wins from 16 input channels on (67.3 vs 66.0 ms per step with the
+        # 16 -> 128 layers native); the input-gradient conv of a 16-channel output gradient (conv6: one K chunk into 256
+        # channels, 255 vs 207 us) does not
         fx = dx = None
         if cout > 16:
             fx = torch.empty(lib.scm_conv3x3_pack_x3_bytes(cin, cout) // 2, device=w.device, dtype=torch.int16)
-        if cin > 16:
+        if cin > 16 and cout >= 32:
             dx = torch.empty(lib.scm_conv3x3_pack_x3_bytes(cout, cin) // 2, device=w.device, dtype=torch.int16)
         if fx is not None or dx is not None:
             L.check(lib.scm_pack_conv3x3_weights_x3(_p(w), cin, cout, int(transposed), cin_total, ci0, _p(fx), _p(dx),
