@@ -403,6 +403,30 @@ def main():
                                "share_of_step": s["ms"] / (dt * 1e3)}
             out["kernels"] = {k: {"launches": v["launches"], "ms_total": round(v["ms"], 3),
                                   "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12} for k, v in summ.items()}
+        if world == 1 and not a.profile_mode and a.precision == "fp32" and a.size <= 64:
+            # The same iteration with the 3x3 convolutions' fp32 arithmetic emulated on the bf16 MFMA pipe (exact 3-way
+            # bf16 split of both operands, six partial products per product, fp32 accumulation: DESIGN.md section 4e).
+            # NOT `value`: reported beside it, with the evidence that it is fp32-grade (tests/test_gpu_x3_mode.py; the
+            # whole -m gpu parity suite passes in this mode at unchanged tolerances).
+            ops.set_compute_precision("fp32x3")
+            enc2, dec2, rp2, disc2, tr2 = build_nets(0)
+            tr2.seed_noise(1234)
+            trainer2 = M.Trainer(L, A, R, enc2, dec2, rp2, disc2, tr2, opts)
+            for i in range(3):
+                trainer2.step(*batches[i % 2], theta=0.5, train_iter=i + 1)
+            torch.cuda.synchronize()
+            n2 = 10
+            t2 = time.perf_counter()
+            for i in range(n2):
+                trainer2.step(*batches[i % 2], theta=0.5, train_iter=i + 4)
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t2
+            ops.set_compute_precision("fp32")
+            out["fp32x3"] = {"value": a.batch * (a.horizon - 2) * n2 / dt2, "unit": "frames/s", "ms_per_step": dt2 / n2 * 1e3,
+                             "steps": n2, "opt_in": "bench.py --precision fp32x3 / main.py --precision fp32x3",
+                             "arithmetic": "fp32 operands split exactly into 3 bf16 values, 6 bf16 MFMA products per term, "
+                                           "fp32 accumulate; error vs float64 within 2.5x of the native f32 MFMA kernels'"}
+            del trainer2, enc2, dec2, rp2, disc2, tr2
         if world == 1 and not a.profile_mode:
             out["decoder"] = decoder_leg(dev, a.batch)
         if world == 1 and headline and not a.profile_mode:
