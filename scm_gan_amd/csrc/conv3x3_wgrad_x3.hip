@@ -36,6 +36,11 @@ __device__ __forceinline__ void wsplit3_pair(float x0, float x1, unsigned& hi, u
 #define X3W_XG (X3W_NG + 2)            // groups incl. one halo unit on each side
 #define X3W_XCOMP (X3W_XG * X3W_XP)    // units per component of an x row slot
 #define X3W_XSLOT (3 * X3W_XCOMP)
+// The shifted fragments need the last dword of the previous unit and the first dword of the next one.  Read out of the
+// 16-byte units those are stride-4 dword reads (4-way bank conflicts, 46 % of the kernel's LDS cycles); they are kept a
+// second time in dense dword arrays instead: [slot][comp][first | last][group][ci pitch 33].
+#define X3W_ECOMP (2 * X3W_XG * X3W_XP)        // dwords per component of a slot
+#define X3W_ESLOT (3 * X3W_ECOMP)
 #define X3W_DP 129                     // co pitch of the dyp image
 #define X3W_DCOMP (X3W_NG * X3W_DP)
 
@@ -44,6 +49,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wgrad_x3_kernel(const WgradKAr
     extern __shared__ __attribute__((aligned(16))) u32x4w wsx[];
     u32x4w* xs = wsx;                          // [4 slots][3 comps][X3W_XG][X3W_XP]
     u32x4w* dsm = wsx + 4 * X3W_XSLOT;         // [3 comps][X3W_NG][X3W_DP]
+    unsigned* xe = reinterpret_cast<unsigned*>(dsm + 3 * X3W_DCOMP);      // edge dwords, see X3W_ECOMP
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -171,26 +177,28 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wgrad_x3_kernel(const WgradKAr
             wsplit3_pair(v[7], v[8], hh[3], mm[3], ll[3]);
             wsplit3_pair(v[9], v[0], hh[4], mm[4], ll[4]);      // low half = p0+8 (right halo), high half = p0-1 (left halo)
             u32x4w* slot = xs + ((r + 1) & 3) * X3W_XSLOT + (xg + 1) * X3W_XP + xc;
+            unsigned* es = xe + ((r + 1) & 3) * X3W_ESLOT + (xg + 1) * X3W_XP + xc;
             u32x4w u;
             u[0] = hh[0]; u[1] = hh[1]; u[2] = hh[2]; u[3] = hh[3];
             slot[0] = u;
+            es[0] = hh[0]; es[X3W_XG * X3W_XP] = hh[3];
             u[0] = mm[0]; u[1] = mm[1]; u[2] = mm[2]; u[3] = mm[3];
             slot[X3W_XCOMP] = u;
+            es[X3W_ECOMP] = mm[0]; es[X3W_ECOMP + X3W_XG * X3W_XP] = mm[3];
             u[0] = ll[0]; u[1] = ll[1]; u[2] = ll[2]; u[3] = ll[3];
             slot[2 * X3W_XCOMP] = u;
-            if (xg == 0) {                              // left halo unit: element 7 = pixel x0 - 1
-                u32x4w* hs = slot - X3W_XP;
-                u[0] = 0u; u[1] = 0u; u[2] = 0u;
-                u[3] = hh[4] & 0xffff0000u; hs[0] = u;
-                u[3] = mm[4] & 0xffff0000u; hs[X3W_XCOMP] = u;
-                u[3] = ll[4] & 0xffff0000u; hs[2 * X3W_XCOMP] = u;
+            es[2 * X3W_ECOMP] = ll[0]; es[2 * X3W_ECOMP + X3W_XG * X3W_XP] = ll[3];
+            if (xg == 0) {                              // left halo unit: its last dword = (.., pixel x0 - 1)
+                unsigned* hs = es - X3W_XP + X3W_XG * X3W_XP;
+                hs[0] = hh[4] & 0xffff0000u;
+                hs[X3W_ECOMP] = mm[4] & 0xffff0000u;
+                hs[2 * X3W_ECOMP] = ll[4] & 0xffff0000u;
             }
-            if (xg == X3W_NG - 1) {                     // right halo unit: element 0 = pixel x0 + 64
-                u32x4w* hs = slot + X3W_XP;
-                u[1] = 0u; u[2] = 0u; u[3] = 0u;
-                u[0] = hh[4] & 0xffffu; hs[0] = u;
-                u[0] = mm[4] & 0xffffu; hs[X3W_XCOMP] = u;
-                u[0] = ll[4] & 0xffffu; hs[2 * X3W_XCOMP] = u;
+            if (xg == X3W_NG - 1) {                     // right halo unit: its first dword = (pixel x0 + 64, ..)
+                unsigned* hs = es + X3W_XP;
+                hs[0] = hh[4] & 0xffffu;
+                hs[X3W_ECOMP] = mm[4] & 0xffffu;
+                hs[2 * X3W_ECOMP] = ll[4] & 0xffffu;
             }
         };
         auto fetch_d = [&](int y) {
@@ -254,12 +262,13 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wgrad_x3_kernel(const WgradKAr
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky) {
                     const u32x4w* xr = xs + ((y + ky) & 3) * X3W_XSLOT + (g + 1) * X3W_XP + l31;
+                    const unsigned* er = xe + ((y + ky) & 3) * X3W_ESLOT + (g + 1) * X3W_XP + l31;
                     u32x4w f0[3], f1[3], f2[3];
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
                         const u32x4w u = xr[c * X3W_XCOMP];
-                        const unsigned pw = reinterpret_cast<const unsigned*>(xr + c * X3W_XCOMP - X3W_XP)[3];   // previous unit, pixels 6..7
-                        const unsigned nx = reinterpret_cast<const unsigned*>(xr + c * X3W_XCOMP + X3W_XP)[0];   // next unit, pixels 0..1
+                        const unsigned pw = er[c * X3W_ECOMP + X3W_XG * X3W_XP - X3W_XP];    // previous unit, pixels 6..7
+                        const unsigned nx = er[c * X3W_ECOMP + X3W_XP];                       // next unit, pixels 0..1
                         const unsigned s01 = __builtin_amdgcn_alignbit(u[1], u[0], 16);
                         const unsigned s12 = __builtin_amdgcn_alignbit(u[2], u[1], 16);
                         const unsigned s23 = __builtin_amdgcn_alignbit(u[3], u[2], 16);
@@ -320,7 +329,7 @@ int scm_launch_wgrad_x3(const WgradKArgs& k, const WgradPlan& p, hipStream_t s) 
     const bool vec = (a.W % 4 == 0) && (a.PS % 8 == 0) &&
                      ((reinterpret_cast<size_t>(a.x1) | reinterpret_cast<size_t>(a.x2) | reinterpret_cast<size_t>(a.dy) |
                        reinterpret_cast<size_t>(a.gate) | reinterpret_cast<size_t>(a.gate_mask)) % 16 == 0);
-    const size_t lds = ((size_t)4 * X3W_XSLOT + 3 * X3W_DCOMP) * 16;
+    const size_t lds = ((size_t)4 * X3W_XSLOT + 3 * X3W_DCOMP) * 16 + (size_t)4 * X3W_ESLOT * 4;
     const dim3 grid(p.co_groups * a.ci_groups, p.nsplit);
     static std::atomic<uint64_t> attr_done[2];
     if (vec) {

@@ -16,7 +16,7 @@ part = torch.empty(pf.value, device='cuda'); cws = torch.empty(cf.value, device=
 dw = torch.empty_like(w); db = torch.empty(C, device='cuda')
 packs = ops.pack_conv3x3(w, C, C)
 mask = torch.zeros(B, C // 32, H, W, device='cuda', dtype=torch.int32)
-for _ in range(4):
+for _ in range(16):
     y, _ = ops._conv3x3_raw(x, None, None, None, 0, packs[0], C, None, bias, None, C, 1, ops.ACT_LRELU, packs[2], mask_out=mask)
     dx, _ = ops._conv3x3_raw(gy, None, y, None, ops.ACT_LRELU, packs[1], C, None, None, None, C, 1, ops.ACT_NONE, packs[3], mask_in=mask)
     d = L.WgradDesc(P(x), None, C, 0, P(gy), P(y), ops.ACT_LRELU, C, P(dw), P(db), None, P(part), P(cws), B, H, W, 1, 0, 0, 0, 0, None, None, P(mask))
