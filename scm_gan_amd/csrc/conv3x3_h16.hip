@@ -254,6 +254,8 @@ __global__ void __launch_bounds__(256, 1) conv3x3_h16_kernel(const ConvKArgs a) 
 
     // ---- epilogue (as conv3x3_mfma.hip): scale, bias, per-sample bias, activation, NCHW store
     const float sc = a.scale ? *a.scale : 1.f;
+    const bool sigmoid = a.act == SCM_ACT_SIGMOID;     // one branch per loop nest, not per value (common.h)
+    const float slope = scm_act_slope(a.act);
     const int co2n = a.cout - a.co1;
     // bias + per-sample bias of this workgroup's channels were put into an LDS table by the
     // prologue: 16*CT broadcast LDS reads here instead of 32*CT global loads per thread (~22
@@ -278,11 +280,33 @@ __global__ void __launch_bounds__(256, 1) conv3x3_h16_kernel(const ConvKArgs a) 
     __syncthreads();                                // every wave is done reading the stage buffers
 #pragma unroll
     for (int m = 0; m < CT; ++m) {
+        // accumulate_y1: the values already in y1, ALL requested before anything waits on one of them (one
+        // load-add-store per row in turn costs a memory round trip each: +200 us on a 128 -> 128 input gradient)
+        f32x4 old[16];
+        if (a.acc_y1 && vec) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            for (int k = 0; k < 16; ++k) {
+                const int co = cg * CW + m * 32 + 2 * k + lh;
+                const int p = p0 + wave * NPW + 4 * l31;
+                const bool take = co < a.co1 && co < a.cout && p + 3 < HW;
+                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                old[k] = take ? *reinterpret_cast<const f32x4*>(a.y1 + ((size_t)b * a.co1 + co) * HW + p) : zero;
+            }
+        }
+        if (sigmoid) {
 #pragma unroll
-            for (int n = 0; n < PT; ++n) ep[row * EP + n * 32 + l31] = scm_act(acc[m][n][r] * sc + badd[m][r], a.act);
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+#pragma unroll
+                for (int n = 0; n < PT; ++n) ep[row * EP + n * 32 + l31] = scm_sigmoid(acc[m][n][r] * sc + badd[m][r]);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+#pragma unroll
+                for (int n = 0; n < PT; ++n) ep[row * EP + n * 32 + l31] = scm_act_sel(acc[m][n][r] * sc + badd[m][r], slope);
+            }
         }
         __syncthreads();
         unsigned bits[4] = {0u, 0u, 0u, 0u};        // sign bits of this lane's rows, per pixel of its float4
@@ -300,7 +324,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_h16_kernel(const ConvKArgs a) 
                 const bool add = a.acc_y1 && co < a.co1;
                 if (vec && p + 3 < HW) {
                     f32x4 o = v;
-                    if (add) o += *reinterpret_cast<const f32x4*>(dst);
+                    if (add) o += old[k];
                     *reinterpret_cast<f32x4*>(dst) = o;
                 } else {
 #pragma unroll

@@ -17,6 +17,7 @@
 // the im2col as an address offset, register prefetch of the next chunk, unconditional
 // clamped loads with select masks, act' gate applied on load for the backward pass.
 #include "conv_args.h"
+#include <type_traits>
 
 #define M16_PT 8     // 16-pixel tiles per wave
 
@@ -170,6 +171,8 @@ __global__ void __launch_bounds__(256, 2) conv3x3_m16_kernel(const ConvKArgs a) 
 
     // ---- epilogue
     const float sc = a.scale ? *a.scale : 1.f;
+    const bool sigmoid = a.act == SCM_ACT_SIGMOID;
+    const float slope = scm_act_slope(a.act);
     float badd[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -180,22 +183,42 @@ __global__ void __launch_bounds__(256, 2) conv3x3_m16_kernel(const ConvKArgs a) 
         if (a.sbias) badd[r] += a.sbias[(size_t)b * a.cout + coc];
     }
     const int co2n = a.cout - a.co1;
+    // accumulate_y1: the values already in y1, all requested before anything waits on one of them
+    float old[4][M16_PT];
+    if (a.acc_y1) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int co = 4 * lq + r;
-        if (co < a.cout) {
-            float* dst = co < a.co1 ? a.y1 + ((size_t)b * a.co1 + co) * HW
-                                    : a.y2 + ((size_t)b * co2n + (co - a.co1)) * HW;
+        for (int r = 0; r < 4; ++r) {
+            const int co = 4 * lq + r;
+            const float* src = a.y1 + ((size_t)b * a.co1 + (co < a.co1 ? co : 0)) * HW;
 #pragma unroll
             for (int t = 0; t < M16_PT; ++t) {
                 const int p = p0 + wave * NPW + t * 16 + l15;
-                if (p < HW) {
-                    const float v = scm_act(acc[t][r] * sc + badd[r], a.act);
-                    dst[p] = (a.acc_y1 && co < a.co1) ? dst[p] + v : v;
-                }
+                old[r][t] = (co < a.co1 && co < a.cout && p < HW) ? src[p] : 0.f;
             }
         }
     }
+    auto write_out = [&](auto sigc) {
+        constexpr bool SIG = decltype(sigc)::value;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = 4 * lq + r;
+            if (co < a.cout) {
+                float* dst = co < a.co1 ? a.y1 + ((size_t)b * a.co1 + co) * HW
+                                        : a.y2 + ((size_t)b * co2n + (co - a.co1)) * HW;
+#pragma unroll
+                for (int t = 0; t < M16_PT; ++t) {
+                    const int p = p0 + wave * NPW + t * 16 + l15;
+                    if (p < HW) {
+                        const float u = acc[t][r] * sc + badd[r];
+                        const float v = SIG ? scm_sigmoid(u) : scm_act_sel(u, slope);
+                        dst[p] = (a.acc_y1 && co < a.co1) ? old[r][t] + v : v;
+                    }
+                }
+            }
+        }
+    };
+    if (sigmoid) write_out(std::true_type{});
+    else write_out(std::false_type{});
 }
 
 template <int NJ, int GATED>

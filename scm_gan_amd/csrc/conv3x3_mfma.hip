@@ -255,6 +255,8 @@ __global__ void __launch_bounds__(256, WPS) conv3x3_mfma_kernel(const ConvKArgs 
     // index) and all in flight together: loading bias[co] inside the guarded store
     // loop cost one serialized L2 round trip per accumulator register (45 us / WG).
     const float sc = a.scale ? *a.scale : 1.f;
+    const bool sigmoid = a.act == SCM_ACT_SIGMOID;     // one branch per loop nest, not per value (common.h)
+    const float slope = scm_act_slope(a.act);
     const int co2n = a.cout - a.co1;
     // bias + per-sample bias come from the LDS table the prologue filled: 16*CT broadcast LDS
     // reads instead of up to 32*CT global loads per thread
@@ -279,15 +281,37 @@ __global__ void __launch_bounds__(256, WPS) conv3x3_mfma_kernel(const ConvKArgs 
         __syncthreads();                                // every wave is done reading the stage
 #pragma unroll
         for (int m = 0; m < CT; ++m) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-#pragma unroll
-                for (int n = 0; n < PT; ++n) ep[row * EP + n * 32 + l31] = scm_act(acc[m][n][r] * sc + badd[m][r], a.act);
-            }
-            __syncthreads();
             constexpr int Q4 = NPW / 4;                 // float4s per channel row of the slab
             constexpr int RP = 64 / Q4;                 // rows per wave instruction
+            // accumulate_y1: the values already in y1, ALL requested before anything waits on one of them (one
+            // load-add-store per row in turn costs a memory round trip each)
+            f32x4 old[32 / RP];
+            if (a.acc_y1 && vec) {
+#pragma unroll
+                for (int k = 0; k < 32 / RP; ++k) {
+                    const int co = cg * CW + m * 32 + RP * k + lane / Q4;
+                    const int p = p0 + wave * NPW + 4 * (lane % Q4);
+                    const bool take = co < a.co1 && co < a.cout && p + 3 < HW;
+                    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                    old[k] = take ? *reinterpret_cast<const f32x4*>(a.y1 + ((size_t)b * a.co1 + co) * HW + p) : zero;
+                }
+            }
+            if (sigmoid) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+#pragma unroll
+                    for (int n = 0; n < PT; ++n) ep[row * EP + n * 32 + l31] = scm_sigmoid(acc[m][n][r] * sc + badd[m][r]);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+#pragma unroll
+                    for (int n = 0; n < PT; ++n) ep[row * EP + n * 32 + l31] = scm_act_sel(acc[m][n][r] * sc + badd[m][r], slope);
+                }
+            }
+            __syncthreads();
             unsigned bits[4] = {0u, 0u, 0u, 0u};        // sign bits of this lane's rows, per pixel of its float4
 #pragma unroll
             for (int k = 0; k < 32 / RP; ++k) {
@@ -304,7 +328,7 @@ __global__ void __launch_bounds__(256, WPS) conv3x3_mfma_kernel(const ConvKArgs 
                     const bool add = a.acc_y1 && co < a.co1;
                     if (vec && p + 3 < HW) {
                         f32x4 o = v;
-                        if (add) o += *reinterpret_cast<const f32x4*>(dst);
+                        if (add) o += old[k];
                         *reinterpret_cast<f32x4*>(dst) = o;
                     } else {
 #pragma unroll
@@ -340,25 +364,31 @@ __global__ void __launch_bounds__(256, WPS) conv3x3_mfma_kernel(const ConvKArgs 
         return;
     }
     const int pbase = p0 + wave * NPW + l31;
+    auto write_out = [&](auto sigc) {
+        constexpr bool SIG = decltype(sigc)::value;
 #pragma unroll
-    for (int m = 0; m < CT; ++m) {
+        for (int m = 0; m < CT; ++m) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = cg * CW + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (co < a.cout) {
-                float* dst = co < a.co1 ? a.y1 + ((size_t)b * a.co1 + co) * HW
-                                        : a.y2 + ((size_t)b * co2n + (co - a.co1)) * HW;
+            for (int r = 0; r < 16; ++r) {
+                const int co = cg * CW + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (co < a.cout) {
+                    float* dst = co < a.co1 ? a.y1 + ((size_t)b * a.co1 + co) * HW
+                                            : a.y2 + ((size_t)b * co2n + (co - a.co1)) * HW;
 #pragma unroll
-                for (int n = 0; n < PT; ++n) {
-                    const int p = pbase + n * 32;
-                    if (p < HW) {
-                        const float v = scm_act(acc[m][n][r] * sc + badd[m][r], a.act);
-                        dst[p] = (a.acc_y1 && co < a.co1) ? dst[p] + v : v;
+                    for (int n = 0; n < PT; ++n) {
+                        const int p = pbase + n * 32;
+                        if (p < HW) {
+                            const float t = acc[m][n][r] * sc + badd[m][r];
+                            const float v = SIG ? scm_sigmoid(t) : scm_act_sel(t, slope);
+                            dst[p] = (a.acc_y1 && co < a.co1) ? dst[p] + v : v;
+                        }
                     }
                 }
             }
         }
-    }
+    };
+    if (sigmoid) write_out(std::true_type{});
+    else write_out(std::false_type{});
 }
 
 // ------------------------------------------------------------------ pack

@@ -14,6 +14,7 @@
 //     halo tile (74 KB) stay in LDS while the weights pass through in two 64-channel halves (55 KB each): the tile is
 //     fetched and split once per 128 output channels, 135 KB of LDS in all.
 #include "conv_args.h"
+#include <type_traits>
 
 #define XKC 16
 #define X3_CT 2
@@ -38,6 +39,20 @@ __device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& hi, un
     mid = __builtin_bit_cast(unsigned, m);
     lo = __builtin_bit_cast(unsigned, l);
 }
+
+// Phase clock for tools/exp/x3_phases.hip (compiled in only with -DX3_TIMING): shader-clock ticks per phase,
+// summed over the chunks of one wave.
+#ifdef X3_TIMING
+__device__ unsigned long long x3_ticks[8];
+#define X3_TICK(i)                                      \
+    do {                                                \
+        const unsigned long long t_ = clock64();        \
+        t_acc[i] += t_ - t_last;                        \
+        t_last = t_;                                    \
+    } while (0)
+#else
+#define X3_TICK(i)
+#endif
 
 // GATED: 0 plain input, 1 input * act'(gate tensor), 2 input * leaky-relu slope from the 1-bit gate mask
 // CT: 32-channel row tiles per weight half (1 or 2); NH: halves per workgroup (1 or 2)
@@ -134,39 +149,54 @@ __global__ void __launch_bounds__(256, 1) conv3x3_x3_kernel(const ConvKArgs a) {
     unsigned pm[GATED == 2 ? NJ : 1];
     const int mask_nw = (a.c1 + 31) >> 5;
 
-    auto fetch_w = [&](int ci0, int half) {
+    // weight load i of the 3 * WR that make a chunk half; fetch_w issues all of them
+    auto fetch_w_part = [&](int ci0, int half, int i) {
         const u32x4x* wc = wsrc + ((size_t)half * nchunks + ci0 / XKC) * 3 * WU;
-#pragma unroll
-        for (int comp = 0; comp < 3; ++comp)
-#pragma unroll
-            for (int k = 0; k < WR; ++k) {
-                int gi = tid + 256 * k;
-                gi = gi < WU ? gi : WU - 1;
-                pw[comp][k] = wc[comp * WU + gi];
-            }
+        const int comp = i / WR, k = i % WR;
+        int gi = tid + 256 * k;
+        gi = gi < WU ? gi : WU - 1;
+        pw[comp][k] = wc[comp * WU + gi];
     };
-    auto fetch_x = [&](int ci0) {
+    auto fetch_w = [&](int ci0, int half) {
 #pragma unroll
-        for (int c = 0; c < XKC; ++c) {
-            const int ci = ci0 + c;
-            const int cc = ci < cin ? ci : 0;
-            const bool first = cc < a.c1;
-            const size_t o = first ? ((size_t)b * a.c1 + cc) * HW : ((size_t)b * a.c2 + (cc - a.c1)) * HW;
-            const float* src = (first ? a.x1 : a.x2) + o;
+        for (int i = 0; i < 3 * WR; ++i) fetch_w_part(ci0, half, i);
+    };
+    // per-image bases of the two concatenated inputs, indexed by the CONCATENATED channel; pinned in SGPRs (left to
+    // itself the compiler selects between the kernarg slots and re-loads the pointer, with a wait, per channel)
+    // (global address space spelled out: behind the asm the compiler would otherwise fall back to flat loads, which
+    // also count on lgkmcnt and so serialise with the LDS reads of the MFMA loop)
+    typedef const __attribute__((address_space(1))) float* gfp;
+    gfp xb1 = (gfp)(a.x1 + (size_t)b * a.c1 * HW);
+    gfp xb2 = a.c2 ? (gfp)(a.x2 + ((size_t)b * a.c2 - a.c1) * HW) : xb1;
+    gfp gb1 = GATED == 1 ? (gfp)(a.gate1 + (size_t)b * a.c1 * HW) : nullptr;
+    gfp gb2 = (GATED == 1 && a.c2) ? (gfp)(a.gate2 + ((size_t)b * a.c2 - a.c1) * HW) : gb1;
+    asm volatile("" : "+s"(xb1), "+s"(xb2));
+    if constexpr (GATED == 1) asm volatile("" : "+s"(gb1), "+s"(gb2));
+    auto fetch_x_ch = [&](int ci0, int c) {
+        const int ci = ci0 + c;
+        const int cc = ci < cin ? ci : 0;
+        const bool first = cc < a.c1;
+        const gfp src = (first ? xb1 : xb2) + (size_t)cc * HW;
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) px[c][j] = src[goff[j]];
-            if constexpr (GATED == 1) {
-                const float* gsrc = (first ? a.gate1 : a.gate2) + o;
+        for (int j = 0; j < NJ; ++j) px[c][j] = src[goff[j]];
+        if constexpr (GATED == 1) {
+            const gfp gsrc = (first ? gb1 : gb2) + (size_t)cc * HW;
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) pg[c][j] = gsrc[goff[j]];
-            }
+            for (int j = 0; j < NJ; ++j) pg[c][j] = gsrc[goff[j]];
         }
+    };
+    auto fetch_mask = [&](int ci0) {
         if constexpr (GATED == 2) {
             const int w = (ci0 < cin ? ci0 : 0) >> 5;
             const unsigned* mrow = a.mask_in + ((size_t)b * mask_nw + w) * HW;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) pm[j] = mrow[goff[j]];
         }
+    };
+    auto fetch_x = [&](int ci0) {
+#pragma unroll
+        for (int c = 0; c < XKC; ++c) fetch_x_ch(ci0, c);
+        fetch_mask(ci0);
     };
     auto store_w = [&]() {
 #pragma unroll
@@ -205,59 +235,104 @@ __global__ void __launch_bounds__(256, 1) conv3x3_x3_kernel(const ConvKArgs a) {
         }
     };
 
-    auto mfma_half = [&](int half) {
+    auto mfma_half = [&](int half, auto&& after_tap) {
         const u32x4x* wl = smx;
         const u32x4x* xl = smx + 3 * WCOMP;
+        // Operands are read ahead of the products that use them (one wave per SIMD: nothing else would cover the LDS
+        // latency): the pixels of the next 32-pixel tile are in flight under the current tile's 6*CT MFMAs, and each
+        // weight component of tap t+1 replaces tap t's as soon as that one's last product has been issued.  Products
+        // per accumulator stay in the fixed order lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi; consecutive MFMAs go
+        // to different accumulators.
+        u32x4x av[3][CT], bv[2][3];
+        auto load_a = [&](int tap, int comp) {
+#pragma unroll
+            for (int m = 0; m < CT; ++m) av[comp][m] = wl[comp * WCOMP + ((tap * 2 + lh) * CT + m) * 32 + l31];
+        };
+        auto load_b = [&](int step) {
+            const int tap = step / PT, n = step % PT;
+            const int toff = (tap / 3) * ROWPL + (tap % 3);
+#pragma unroll
+            for (int comp = 0; comp < 3; ++comp) bv[step & 1][comp] = xl[comp * XCOMP + baddr[n] + toff];
+        };
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+        constexpr int LAST_USE[3] = {5, 3, 0};          // product after which a weight component is dead
+        load_a(0, 0); load_a(0, 1); load_a(0, 2);
+        load_b(0);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            const int toff = (tap / 3) * ROWPL + (tap % 3);
-            u32x4x av[3][CT], bv[3][PT];
 #pragma unroll
-            for (int comp = 0; comp < 3; ++comp) {
+            for (int n = 0; n < PT; ++n) {
+                const int step = tap * PT + n;
+                if (step + 1 < 9 * PT) load_b(step + 1);
 #pragma unroll
-                for (int m = 0; m < CT; ++m) av[comp][m] = wl[comp * WCOMP + ((tap * 2 + lh) * CT + m) * 32 + l31];
+                for (int q = 0; q < 6; ++q) {
 #pragma unroll
-                for (int n = 0; n < PT; ++n) bv[comp][n] = xl[comp * XCOMP + baddr[n] + toff];
-            }
-#pragma unroll
-            for (int m = 0; m < CT; ++m)
-#pragma unroll
-                for (int n = 0; n < PT; ++n) {
-                    f32x16 c = acc[half * CT + m][n];
-                    c = mfma_bf16(av[2][m], bv[0][n], c);      // lo * hi
-                    c = mfma_bf16(av[0][m], bv[2][n], c);      // hi * lo
-                    c = mfma_bf16(av[1][m], bv[1][n], c);      // mid * mid
-                    c = mfma_bf16(av[1][m], bv[0][n], c);      // mid * hi
-                    c = mfma_bf16(av[0][m], bv[1][n], c);      // hi * mid
-                    c = mfma_bf16(av[0][m], bv[0][n], c);      // hi * hi
-                    acc[half * CT + m][n] = c;
+                    for (int m = 0; m < CT; ++m)
+                        acc[half * CT + m][n] = mfma_bf16(av[PA[q]][m], bv[step & 1][PB[q]], acc[half * CT + m][n]);
+                    if (n == PT - 1 && tap + 1 < 9 && q == LAST_USE[PA[q]]) load_a(tap + 1, PA[q]);
                 }
+                __builtin_amdgcn_sched_barrier(0);      // keep the read-ahead at one step (registers)
+            }
+            after_tap(tap);
         }
     };
 
+#ifdef X3_TIMING
+    unsigned long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t_last = clock64();
+#endif
     fetch_x(0);
     fetch_w(0, 0);
+    X3_TICK(0);
     for (int ci0 = 0; ci0 < cin; ci0 += XKC) {
         __syncthreads();                    // the previous chunk's products are done with both images
+        X3_TICK(1);
         store_x(ci0);
         store_w();
+        X3_TICK(2);
         __syncthreads();
+        X3_TICK(1);
+        // The global loads of the next stage are spread over the taps of the running one: issued in one burst they
+        // fill the memory pipeline's queues and the wave waits ~50 cycles per load with its MFMAs stopped
+        // (tools/exp/x3_phases.hip); a few per tap go out for free.
         if constexpr (NH == 2) {
-            fetch_w(ci0, 1);                // second half of this chunk's weights, in flight under the first half's MFMAs
-            mfma_half(0);
+            mfma_half(0, [&](int tap) {     // second half of this chunk's weights, needed when this half is done
+                constexpr int PER = (3 * WR + 4) / 5;
+                if (tap < 5) {
+#pragma unroll
+                    for (int i = tap * PER; i < (tap + 1) * PER && i < 3 * WR; ++i) fetch_w_part(ci0, 1, i);
+                }
+            });
+            X3_TICK(3);
             __syncthreads();                // every wave is done with the first half's weights
+            X3_TICK(1);
             store_w();
+            X3_TICK(4);
             __syncthreads();
+            X3_TICK(1);
         }
-        if (ci0 + XKC < cin) {
-            fetch_x(ci0 + XKC);
-            fetch_w(ci0 + XKC, 0);
-        }
-        mfma_half(NH - 1);
+        const bool more = ci0 + XKC < cin;
+        X3_TICK(5);
+        mfma_half(NH - 1, [&](int tap) {    // the next chunk's pixels and first weight half
+            if (more) {
+                constexpr int CPT = XKC / 8, WPT = (3 * WR + 7) / 8;
+                if (tap < 8) {
+#pragma unroll
+                    for (int c = tap * CPT; c < (tap + 1) * CPT; ++c) fetch_x_ch(ci0 + XKC, c);
+#pragma unroll
+                    for (int i = tap * WPT; i < (tap + 1) * WPT && i < 3 * WR; ++i) fetch_w_part(ci0 + XKC, 0, i);
+                } else {
+                    fetch_mask(ci0 + XKC);
+                }
+            }
+        });
+        X3_TICK(6);
     }
 
     // ---- epilogue (as conv3x3_h16.hip)
     const float sc = a.scale ? *a.scale : 1.f;
+    const bool sigmoid = a.act == SCM_ACT_SIGMOID;
+    const float slope = scm_act_slope(a.act);
     const int co2n = a.cout - a.co1;
     float badd[NH * CT][16];
     {
@@ -274,11 +349,33 @@ __global__ void __launch_bounds__(256, 1) conv3x3_x3_kernel(const ConvKArgs a) {
     __syncthreads();
 #pragma unroll
     for (int m = 0; m < NH * CT; ++m) {
+        // accumulate_y1: the values already in y1, ALL requested before anything waits on one of them (one
+        // load-add-store per row in turn costs a memory round trip each: +200 us on a 128 -> 128 input gradient)
+        f32x4 old[16];
+        if (a.acc_y1 && vec) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            for (int k = 0; k < 16; ++k) {
+                const int co = cg * CW + m * 32 + 2 * k + lh;
+                const int p = p0 + wave * NPW + 4 * l31;
+                const bool take = co < a.co1 && co < a.cout && p + 3 < HW;
+                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                old[k] = take ? *reinterpret_cast<const f32x4*>(a.y1 + ((size_t)b * a.co1 + co) * HW + p) : zero;
+            }
+        }
+        if (sigmoid) {
 #pragma unroll
-            for (int n = 0; n < PT; ++n) ep[row * EP + n * 32 + l31] = scm_act(acc[m][n][r] * sc + badd[m][r], a.act);
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+#pragma unroll
+                for (int n = 0; n < PT; ++n) ep[row * EP + n * 32 + l31] = scm_sigmoid(acc[m][n][r] * sc + badd[m][r]);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+#pragma unroll
+                for (int n = 0; n < PT; ++n) ep[row * EP + n * 32 + l31] = scm_act_sel(acc[m][n][r] * sc + badd[m][r], slope);
+            }
         }
         __syncthreads();
         unsigned bits[4] = {0u, 0u, 0u, 0u};
@@ -290,13 +387,17 @@ __global__ void __launch_bounds__(256, 1) conv3x3_x3_kernel(const ConvKArgs a) {
             const int p = p0 + wave * NPW + 4 * l31;
 #pragma unroll
             for (int i = 0; i < 4; ++i) bits[i] |= (v[i] > 0.f ? 1u : 0u) << row;
+#ifdef X3_NOSTORE
+            if (co < a.cout && v[0] == 12345.f) {
+#else
             if (co < a.cout) {
+#endif
                 float* dst = (co < a.co1 ? a.y1 + ((size_t)b * a.co1 + co) * HW
                                          : a.y2 + ((size_t)b * co2n + (co - a.co1)) * HW) + p;
                 const bool add = a.acc_y1 && co < a.co1;
                 if (vec && p + 3 < HW) {
                     f32x4 o = v;
-                    if (add) o += *reinterpret_cast<const f32x4*>(dst);
+                    if (add) o += old[k];
                     *reinterpret_cast<f32x4*>(dst) = o;
                 } else {
 #pragma unroll
@@ -325,6 +426,11 @@ __global__ void __launch_bounds__(256, 1) conv3x3_x3_kernel(const ConvKArgs a) {
         }
         if (m + 1 < NH * CT) __syncthreads();
     }
+    X3_TICK(7);
+#ifdef X3_TIMING
+    if (blockIdx.x == X3_TIMING && blockIdx.y == 0 && tid == 0)
+        for (int i = 0; i < 8; ++i) x3_ticks[i] = t_acc[i];
+#endif
 }
 
 // ------------------------------------------------------------------ pack
