@@ -12,6 +12,7 @@
 //     its neighbours with five v_alignbit_b32 per (row, component);
 //   * 128 co x 32 ci per workgroup, 4 waves (one per SIMD, the 9 tap accumulators in AGPRs), dy single-buffered.
 #include "wgrad_args.h"
+#include <type_traits>
 
 typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
 typedef __bf16 b16x8w __attribute__((ext_vector_type(8)));
@@ -44,7 +45,23 @@ __device__ __forceinline__ void wsplit3_pair(float x0, float x1, unsigned& hi, u
 #define X3W_DP 129                     // co pitch of the dyp image
 #define X3W_DCOMP (X3W_NG * X3W_DP)
 
-template <bool VEC>
+// Phase clock for tools/exp/x3w_phases.hip (compiled in only with -DX3W_TIMING): shader-clock ticks per phase of wave 0
+#ifdef X3W_TIMING
+__device__ unsigned long long x3w_ticks[8];
+#define X3W_TICK(i)                                     \
+    do {                                                \
+        const unsigned long long t_ = clock64();        \
+        t_acc[i] += t_ - t_last;                        \
+        t_last = t_;                                    \
+    } while (0)
+#else
+#define X3W_TICK(i)
+#endif
+
+// VEC: 16-byte loads and whole 8-pixel groups (see store_x); NKS: 16-pixel MFMA steps per row segment, known at
+// compile time for the VEC kernels (the step loop is unrolled so that the next row's loads can be dealt out over the
+// steps without conditional register merges), 0 = run-time
+template <bool VEC, int NKS>
 __global__ void __launch_bounds__(256, 1) conv3x3_wgrad_x3_kernel(const WgradKArgs a) {
     extern __shared__ __attribute__((aligned(16))) u32x4w wsx[];
     u32x4w* xs = wsx;                          // [4 slots][3 comps][X3W_XG][X3W_XP]
@@ -115,6 +132,10 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wgrad_x3_kernel(const WgradKAr
     float px[10], pe = 0.f;
     float pd[DT][8], pgv[DT][8];
 
+#ifdef X3W_TIMING
+    unsigned long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t_last = clock64();
+#endif
     for (int seg = 0; seg < a.nseg; ++seg) {
         const int x0 = seg * PS;
         int ps = W - x0;
@@ -156,19 +177,36 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wgrad_x3_kernel(const WgradKAr
             px[9] = row[cr];
             // the pixel one past the segment (the kx = 2 tap of its last pixel): wherever it falls in this thread's
             // ten, it is the wrapped column under circular padding -- load8 clamps instead of wrapping
-            int ce = x0 + ps;
-            if (circ) ce = ce >= W ? ce - W : ce;
-            pe = row[ce < W ? ce : W - 1];
+            if constexpr (!VEC) {
+                int ce = x0 + ps;
+                if (circ) ce = ce >= W ? ce - W : ce;
+                pe = row[ce < W ? ce : W - 1];
+            }
         };
+        // VEC kernels (W == nseg * PS, PS % 8 == 0): an 8-pixel group lies wholly inside or wholly outside the segment,
+        // and the pixel one past the segment is px[9] of its last group (fetch_x wraps / clamps it).  Validity is then
+        // three per-thread bit masks (whole group, left halo pixel, right halo pixel) and one wave-uniform row mask.
+        const unsigned xm_all = (xvalid && 8 * xg < ps) ? ~0u : 0u;
+        const unsigned xm_l = (circ || xc0 > 0) ? xm_all : 0u;
+        const unsigned xm_r = (circ || xc0 + 8 < W) ? xm_all : 0u;
         auto store_x = [&](int r) {
-            bool rok = xvalid;
-            if (!circ) rok = rok && r >= 0 && r < H;
             float v[10];
+            if constexpr (VEC) {
+                const unsigned rowm = (circ || (r >= 0 && r < H)) ? ~0u : 0u;
+                const unsigned ma = xm_all & rowm;
+                v[0] = __uint_as_float(__float_as_uint(px[0]) & (xm_l & rowm));
 #pragma unroll
-            for (int i = 0; i < 10; ++i) {
-                const int c = xc0 - 1 + i;
-                const bool ok = rok && (circ || (c >= 0 && c < W)) && (c < x0 + ps + 1);
-                v[i] = ok ? (c == x0 + ps ? pe : px[i]) : 0.f;
+                for (int i = 1; i < 9; ++i) v[i] = __uint_as_float(__float_as_uint(px[i]) & ma);
+                v[9] = __uint_as_float(__float_as_uint(px[9]) & (xm_r & rowm));
+            } else {
+                bool rok = xvalid;
+                if (!circ) rok = rok && r >= 0 && r < H;
+#pragma unroll
+                for (int i = 0; i < 10; ++i) {
+                    const int c = xc0 - 1 + i;
+                    const bool ok = rok && (circ || (c >= 0 && c < W)) && (c < x0 + ps + 1);
+                    v[i] = ok ? (c == x0 + ps ? pe : px[i]) : 0.f;
+                }
             }
             unsigned hh[5], mm[5], ll[5];           // pairs (v0,v1) (v2.. no: (v1,v2),(v3,v4),(v5,v6),(v7,v8) + halo pair (v0,v9)
             wsplit3_pair(v[1], v[2], hh[0], mm[0], ll[0]);
@@ -181,45 +219,57 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wgrad_x3_kernel(const WgradKAr
             u32x4w u;
             u[0] = hh[0]; u[1] = hh[1]; u[2] = hh[2]; u[3] = hh[3];
             slot[0] = u;
-            es[0] = hh[0]; es[X3W_XG * X3W_XP] = hh[3];
+            // VEC: the group after the segment's last one is all zeros here and must not overwrite the first-dword
+            // entries its neighbour (which holds pixel x0 + ps as its right halo) writes for it below
+            const bool last_group = VEC ? 8 * xg + 8 == ps : xg == X3W_NG - 1;
+            const bool keep_first = !(VEC && 8 * xg == ps);
+            if (keep_first) { es[0] = hh[0]; es[X3W_ECOMP] = mm[0]; es[2 * X3W_ECOMP] = ll[0]; }
+            es[X3W_XG * X3W_XP] = hh[3];
             u[0] = mm[0]; u[1] = mm[1]; u[2] = mm[2]; u[3] = mm[3];
             slot[X3W_XCOMP] = u;
-            es[X3W_ECOMP] = mm[0]; es[X3W_ECOMP + X3W_XG * X3W_XP] = mm[3];
+            es[X3W_ECOMP + X3W_XG * X3W_XP] = mm[3];
             u[0] = ll[0]; u[1] = ll[1]; u[2] = ll[2]; u[3] = ll[3];
             slot[2 * X3W_XCOMP] = u;
-            es[2 * X3W_ECOMP] = ll[0]; es[2 * X3W_ECOMP + X3W_XG * X3W_XP] = ll[3];
+            es[2 * X3W_ECOMP + X3W_XG * X3W_XP] = ll[3];
             if (xg == 0) {                              // left halo unit: its last dword = (.., pixel x0 - 1)
                 unsigned* hs = es - X3W_XP + X3W_XG * X3W_XP;
                 hs[0] = hh[4] & 0xffff0000u;
                 hs[X3W_ECOMP] = mm[4] & 0xffff0000u;
                 hs[2 * X3W_ECOMP] = ll[4] & 0xffff0000u;
             }
-            if (xg == X3W_NG - 1) {                     // right halo unit: its first dword = (pixel x0 + 64, ..)
+            if (last_group) {                           // the unit after the segment: its first dword = (pixel x0 + ps, ..)
                 unsigned* hs = es + X3W_XP;
                 hs[0] = hh[4] & 0xffffu;
                 hs[X3W_ECOMP] = mm[4] & 0xffffu;
                 hs[2 * X3W_ECOMP] = ll[4] & 0xffffu;
             }
         };
+        auto fetch_d_part = [&](int y, int j) {
+            load8(dsrc[j] + (size_t)y * W, dc0, pd[j]);
+            if (gated) load8(gsrc[j] + (size_t)y * W, dc0, pgv[j]);
+        };
         auto fetch_d = [&](int y) {
 #pragma unroll
-            for (int j = 0; j < DT; ++j) {
-                load8(dsrc[j] + (size_t)y * W, dc0, pd[j]);
-                load8(gsrc[j] + (size_t)y * W, dc0, pgv[j]);
-            }
+            for (int j = 0; j < DT; ++j) fetch_d_part(y, j);
         };
-        auto store_d = [&]() {
+        unsigned dm[DT];
+#pragma unroll
+        for (int j = 0; j < DT; ++j) dm[j] = (dvalid[j] && 8 * dg < ps) ? ~0u : 0u;
+        // MODE 0: dyp = dy; 1: dy * act'(gate tensor); 2: dy * leaky-relu slope from the 1-bit gate mask.  One branch per
+        // row on the (wave-uniform) mode, none per element.
+        auto store_d_mode = [&](auto modec) {
+            constexpr int MODE = decltype(modec)::value;
 #pragma unroll
             for (int j = 0; j < DT; ++j) {
                 float v[8];
                 float s = 0.f;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    const int c = dc0 + i;
                     float t = pd[j][i];
-                    if (use_mask) t *= ((__float_as_uint(pgv[j][i]) >> dbit[j]) & 1u) ? 1.f : 0.01f;
-                    else if (gated) t *= scm_act_grad_from_out(pgv[j][i], gate_act);
-                    v[i] = (dvalid[j] && c < x0 + ps) ? t : 0.f;
+                    if constexpr (MODE == 2) t *= ((__float_as_uint(pgv[j][i]) >> dbit[j]) & 1u) ? 1.f : 0.01f;
+                    if constexpr (MODE == 1) t *= scm_act_grad_from_out(pgv[j][i], gate_act);
+                    if constexpr (VEC) v[i] = __uint_as_float(__float_as_uint(t) & dm[j]);
+                    else v[i] = (dvalid[j] && dc0 + i < x0 + ps) ? t : 0.f;
                     s += v[i];
                 }
                 csum[j] += s;
@@ -236,6 +286,11 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wgrad_x3_kernel(const WgradKAr
                 dd[2 * X3W_DCOMP] = ul;
             }
         };
+        auto store_d = [&]() {
+            if (use_mask) store_d_mode(std::integral_constant<int, 2>{});
+            else if (gated) store_d_mode(std::integral_constant<int, 1>{});
+            else store_d_mode(std::integral_constant<int, 0>{});
+        };
 
         __syncthreads();                         // the previous segment's MFMAs are done with the images
         fetch_x(y_begin - 1);
@@ -244,55 +299,100 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wgrad_x3_kernel(const WgradKAr
         store_x(y_begin);
         fetch_x(y_begin + 1);
         fetch_d(y_begin);
+        X3W_TICK(0);
 
         for (int y = y_begin; y < y_end; ++y) {
             store_x(y + 1);
+            X3W_TICK(7);
             store_d();
+            X3W_TICK(1);
             __syncthreads();
-            if (y + 1 < y_end) {
-                fetch_x(y + 2);
-                fetch_d(y + 1);
-            }
+            X3W_TICK(2);
+            // MFMA steps (ks, ky).  The LDS operands of a step are read while the previous step's 54 MFMAs run (one
+            // wave per SIMD: nothing else covers the latency), and the next row's global loads go out a few per ks
+            // instead of in one burst that stalls on the memory pipeline's queues (tools/exp/x3w_phases.hip).
+            const bool more = y + 1 < y_end;
             const u32x4w* dst = dsm + wm * 32 + l31;
-            for (int ks = 0; ks < nks; ++ks) {
+            struct XFrag { u32x4w u[3]; unsigned pw[3], nx[3]; };
+            auto load_xf = [&](XFrag& f, int ks, int ky) {
                 const int g = 2 * ks + lh;
-                u32x4w av[3];
+                const u32x4w* xr = xs + ((y + ky) & 3) * X3W_XSLOT + (g + 1) * X3W_XP + l31;
+                const unsigned* er = xe + ((y + ky) & 3) * X3W_ESLOT + (g + 1) * X3W_XP + l31;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    f.u[c] = xr[c * X3W_XCOMP];
+                    f.pw[c] = er[c * X3W_ECOMP + X3W_XG * X3W_XP - X3W_XP];     // previous unit, pixels 6..7
+                    f.nx[c] = er[c * X3W_ECOMP + X3W_XP];                        // next unit, pixels 0..1
+                }
+            };
+            auto load_av = [&](u32x4w* av, int ks) {
+                const int g = 2 * ks + lh;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) av[c] = dst[c * X3W_DCOMP + g * X3W_DP];
+            };
+            auto products = [&](const XFrag& f, const u32x4w* av, int ky) {
+                u32x4w f0[3], f1[3], f2[3];
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky) {
-                    const u32x4w* xr = xs + ((y + ky) & 3) * X3W_XSLOT + (g + 1) * X3W_XP + l31;
-                    const unsigned* er = xe + ((y + ky) & 3) * X3W_ESLOT + (g + 1) * X3W_XP + l31;
-                    u32x4w f0[3], f1[3], f2[3];
+                for (int c = 0; c < 3; ++c) {
+                    const u32x4w u = f.u[c];
+                    const unsigned s01 = __builtin_amdgcn_alignbit(u[1], u[0], 16);
+                    const unsigned s12 = __builtin_amdgcn_alignbit(u[2], u[1], 16);
+                    const unsigned s23 = __builtin_amdgcn_alignbit(u[3], u[2], 16);
+                    f1[c] = u;
+                    f0[c][0] = __builtin_amdgcn_alignbit(u[0], f.pw[c], 16);        // pixels p-1 .. p+6
+                    f0[c][1] = s01; f0[c][2] = s12; f0[c][3] = s23;
+                    f2[c][0] = s01; f2[c][1] = s12; f2[c][2] = s23;                 // pixels p+1 .. p+8
+                    f2[c][3] = __builtin_amdgcn_alignbit(f.nx[c], u[3], 16);
+                }
+                // fixed order per accumulator: lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi; consecutive MFMAs go to
+                // different accumulators
+                constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        const u32x4w u = xr[c * X3W_XCOMP];
-                        const unsigned pw = er[c * X3W_ECOMP + X3W_XG * X3W_XP - X3W_XP];    // previous unit, pixels 6..7
-                        const unsigned nx = er[c * X3W_ECOMP + X3W_XP];                       // next unit, pixels 0..1
-                        const unsigned s01 = __builtin_amdgcn_alignbit(u[1], u[0], 16);
-                        const unsigned s12 = __builtin_amdgcn_alignbit(u[2], u[1], 16);
-                        const unsigned s23 = __builtin_amdgcn_alignbit(u[3], u[2], 16);
-                        f1[c] = u;
-                        f0[c][0] = __builtin_amdgcn_alignbit(u[0], pw, 16);       // pixels p-1 .. p+6
-                        f0[c][1] = s01; f0[c][2] = s12; f0[c][3] = s23;
-                        f2[c][0] = s01; f2[c][1] = s12; f2[c][2] = s23;           // pixels p+1 .. p+8
-                        f2[c][3] = __builtin_amdgcn_alignbit(nx, u[3], 16);
-                    }
-                    auto six = [&](f32x16 c, const u32x4w* f) {
-                        c = wmfma_bf16(av[2], f[0], c);
-                        c = wmfma_bf16(av[0], f[2], c);
-                        c = wmfma_bf16(av[1], f[1], c);
-                        c = wmfma_bf16(av[1], f[0], c);
-                        c = wmfma_bf16(av[0], f[1], c);
-                        c = wmfma_bf16(av[0], f[0], c);
-                        return c;
-                    };
-                    acc[ky * 3 + 0] = six(acc[ky * 3 + 0], f0);
-                    acc[ky * 3 + 1] = six(acc[ky * 3 + 1], f1);
-                    acc[ky * 3 + 2] = six(acc[ky * 3 + 2], f2);
+                for (int q = 0; q < 6; ++q) {
+                    acc[ky * 3 + 0] = wmfma_bf16(av[PA[q]], f0[PB[q]], acc[ky * 3 + 0]);
+                    acc[ky * 3 + 1] = wmfma_bf16(av[PA[q]], f1[PB[q]], acc[ky * 3 + 1]);
+                    acc[ky * 3 + 2] = wmfma_bf16(av[PA[q]], f2[PB[q]], acc[ky * 3 + 2]);
+                }
+            };
+            XFrag fa, fb, fc;
+            u32x4w av[3], avn[3];
+            if constexpr (NKS == 0) {
+                if (more) {
+                    fetch_x(y + 2);
+                    fetch_d(y + 1);
                 }
             }
+            load_av(av, 0);
+            load_xf(fa, 0, 0);
+            auto step = [&](int ks, int nk) {
+                load_xf(fb, ks, 1);
+                if constexpr (NKS > 0) {
+                    // this step's share of the next row's loads; after the last row the same rows are read again
+                    // (unconditional loads: a branch here would make the compiler wait for them on the spot)
+                    if (ks == 0) fetch_x(more ? y + 2 : y + 1);
+#pragma unroll
+                    for (int j = 0; j < DT; ++j)
+                        if (j >= ks * DT / NKS && j < (ks + 1) * DT / NKS) fetch_d_part(more ? y + 1 : y, j);
+                }
+                products(fa, av, 0);
+                load_xf(fc, ks, 2);
+                products(fb, av, 1);
+                const int kn = ks + 1 < nk ? ks + 1 : ks;      // (the last prefetch is a harmless re-read)
+                load_av(avn, kn);
+                load_xf(fa, kn, 0);
+                products(fc, av, 2);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) av[c] = avn[c];
+            };
+            if constexpr (NKS > 0) {
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) step(ks, NKS);
+            } else {
+                for (int ks = 0; ks < nks; ++ks) step(ks, nks);
+            }
+            X3W_TICK(4);
             __syncthreads();                     // dyp image (single stage) free for the next row
+            X3W_TICK(5);
         }
     }
 
@@ -316,6 +416,11 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wgrad_x3_kernel(const WgradKAr
             if (dg == 0 && co < a.cout) a.csum_part[(size_t)split * a.cout + co] = s;
         }
     }
+    X3W_TICK(6);
+#ifdef X3W_TIMING
+    if (blockIdx.x == 1 && blockIdx.y == X3W_TIMING && tid == 0)
+        for (int i = 0; i < 8; ++i) x3w_ticks[i] = t_acc[i];
+#endif
 }
 
 int scm_launch_wgrad_x3(const WgradKArgs& k, const WgradPlan& p, hipStream_t s) {
@@ -326,19 +431,25 @@ int scm_launch_wgrad_x3(const WgradKArgs& k, const WgradPlan& p, hipStream_t s) 
     WgradKArgs a = k;
     const int cin = a.c1 + a.c2;
     a.ci_groups = (cin + 31) / 32;
-    const bool vec = (a.W % 4 == 0) && (a.PS % 8 == 0) &&
+    const bool vec = (a.W % 4 == 0) && (a.PS % 8 == 0) && (a.W == a.nseg * a.PS) &&
                      ((reinterpret_cast<size_t>(a.x1) | reinterpret_cast<size_t>(a.x2) | reinterpret_cast<size_t>(a.dy) |
                        reinterpret_cast<size_t>(a.gate) | reinterpret_cast<size_t>(a.gate_mask)) % 16 == 0);
     const size_t lds = ((size_t)4 * X3W_XSLOT + 3 * X3W_DCOMP) * 16 + (size_t)4 * X3W_ESLOT * 4;
     const dim3 grid(p.co_groups * a.ci_groups, p.nsplit);
-    static std::atomic<uint64_t> attr_done[2];
-    if (vec) {
-        if (int rc = scm_ensure_lds_attr(reinterpret_cast<const void*>(conv3x3_wgrad_x3_kernel<true>), attr_done[0], 160 * 1024)) return rc;
-        hipLaunchKernelGGL(conv3x3_wgrad_x3_kernel<true>, grid, dim3(256), lds, s, a);
-    } else {
-        if (int rc = scm_ensure_lds_attr(reinterpret_cast<const void*>(conv3x3_wgrad_x3_kernel<false>), attr_done[1], 160 * 1024)) return rc;
-        hipLaunchKernelGGL(conv3x3_wgrad_x3_kernel<false>, grid, dim3(256), lds, s, a);
-    }
+    static std::atomic<uint64_t> attr_done[5];
+    auto launch = [&](auto kern, int slot) -> int {
+        if (int rc = scm_ensure_lds_attr(reinterpret_cast<const void*>(kern), attr_done[slot], 160 * 1024)) return rc;
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+        return SCM_OK;
+    };
+    int rc;
+    if (!vec) rc = launch(conv3x3_wgrad_x3_kernel<false, 0>, 0);
+    else if (a.PS == 64) rc = launch(conv3x3_wgrad_x3_kernel<true, 4>, 4);
+    else if (a.PS == 48) rc = launch(conv3x3_wgrad_x3_kernel<true, 3>, 3);
+    else if (a.PS == 32) rc = launch(conv3x3_wgrad_x3_kernel<true, 2>, 2);
+    else if (a.PS == 16) rc = launch(conv3x3_wgrad_x3_kernel<true, 1>, 1);
+    else rc = launch(conv3x3_wgrad_x3_kernel<false, 0>, 0);      // 8-, 24-, 40-, 56-pixel segments: the general kernel
+    if (rc) return rc;
     SCM_LAUNCH_CHECK("conv3x3_wgrad_x3_kernel");
     return SCM_OK;
 }
