@@ -1,5 +1,5 @@
 """128->128, B=64, 64x64 launches of the hot kernels as the training step issues them (1-bit gate mask on):
-fp32 forward / gated dgrad / wgrad and their 16-bit-operand forms, on preallocated buffers (for rocprofv3 --pmc passes)."""
+fp32 forward / gated dgrad / wgrad, their fp32-on-the-bf16-pipe (fp32x3) and 16-bit-operand forms, on preallocated buffers (for rocprofv3 --pmc passes)."""
 import ctypes, sys, torch
 sys.path.insert(0, '.')
 from scm_gan_amd import _lib as L, ops
@@ -14,9 +14,9 @@ pf, cf = ctypes.c_size_t(), ctypes.c_size_t()
 lib.scm_conv3x3_wgrad_workspace(B, H, W, C, C, ctypes.byref(pf), ctypes.byref(cf))
 part = torch.empty(pf.value, device='cuda'); cws = torch.empty(cf.value, device='cuda')
 dw = torch.empty_like(w); db = torch.empty(C, device='cuda')
-for mode in ('fp32', 'fp16'):
+for mode in ('fp32', 'fp32x3', 'fp16'):
     ops.set_compute_precision(mode)
-    fp, dp, fprec, dprec = ops.pack_conv3x3(w, C, C)
+    fp, dp, fprec, dprec = ops.pack_conv3x3(w, C, C)[:4]
     mask = torch.zeros(B, C // 32, H, W, device='cuda', dtype=torch.int32)
     for _ in range(3):
         y, _ = ops._conv3x3_raw(x, None, None, None, 0, fp, C, None, bias, None, C, 1, ops.ACT_LRELU, fprec, mask_out=mask)
