@@ -22,6 +22,7 @@
 // one workgroup per CU (256 accumulator registers + the prefetch registers of a
 // 16-channel chunk), two LDS stages when they fit.
 #include <type_traits>
+#include <stdlib.h>
 #include "conv_args.h"
 
 #define HKC 16
@@ -51,9 +52,25 @@ __device__ __forceinline__ f32x16 mfma_h16(u32x4 a, u32x4 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b16x8, a), __builtin_bit_cast(b16x8, b), c, 0, 0, 0);
 }
 
+// Phase clock for tools/exp/h16_phases.hip (compiled in only with -DH16_TIMING): shader-clock ticks per phase of wave 0
+#ifdef H16_TIMING
+__device__ unsigned long long h16_ticks[8];
+#define H16_TICK(i)                                     \
+    do {                                                \
+        const unsigned long long t_ = clock64();        \
+        t_acc[i] += t_ - t_last;                        \
+        t_last = t_;                                    \
+    } while (0)
+#else
+#define H16_TICK(i)
+#endif
+
 // GATED: 0 plain input, 1 input * act'(gate tensor), 2 input * leaky-relu slope from the 1-bit gate mask
-template <int PREC, int CT, int PT, int NJ, int GATED>
-__global__ void __launch_bounds__(256, 1) conv3x3_h16_kernel(const ConvKArgs a) {
+// WPS: workgroups per CU (= waves per SIMD).  1: 512-pixel tiles, 256 accumulator registers, two LDS stages when they fit.
+// 2: 256-pixel tiles (PT = 2), one LDS stage -- two workgroups share a CU and drift apart, so one's staging, barriers and
+// epilogue (a third of a workgroup's time at 128 -> 128: the whole chip writing at once) run under the other's MFMAs.
+template <int PREC, int CT, int PT, int NJ, int GATED, int WPS = 1>
+__global__ void __launch_bounds__(256, WPS) conv3x3_h16_kernel(const ConvKArgs a) {
     extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
     constexpr int CW = CT * 32;
     constexpr int WU = 9 * 2 * CT * 32;            // 16-byte units of a weight chunk: [tap][h][m][lane]
@@ -61,7 +78,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_h16_kernel(const ConvKArgs a) 
     constexpr int NPW = PT * 32, NP = 4 * NPW;
     constexpr int PLANE = NJ * 256;                // units per channel half
     constexpr int STAGE = WR * 256 + 2 * PLANE;    // units per LDS stage
-    constexpr bool DB = 2 * STAGE * 16 <= 160 * 1024;
+    constexpr bool DB = WPS == 1 && 2 * STAGE * 16 <= 160 * 1024;
     constexpr int MAIN_U = (DB ? 2 : 1) * STAGE, EP_U = 4 * 32 * (NPW + 4) / 4;
     constexpr int BIAS_U = MAIN_U > EP_U ? MAIN_U : EP_U;     // bias table behind the stages and the epilogue slabs
 
@@ -145,35 +162,61 @@ __global__ void __launch_bounds__(256, 1) conv3x3_h16_kernel(const ConvKArgs a) 
     unsigned pm[GATED == 2 ? NJ : 1];
     const int mask_nw = (a.c1 + 31) >> 5;
 
-    auto fetch = [&](int ci0) {
+    // per-image bases of the two concatenated inputs, indexed by the CONCATENATED channel; pinned in SGPRs (left to
+    // itself the compiler selects between the kernarg slots and re-loads the pointer, with a wait, per channel) and
+    // spelled out as global address space (behind the asm it would otherwise fall back to flat loads, which also count
+    // on lgkmcnt and so serialise with the LDS reads of the MFMA loop)
+    typedef const __attribute__((address_space(1))) float* gfp;
+    gfp xb1 = (gfp)(a.x1 + (size_t)b * a.c1 * HW);
+    gfp xb2 = a.c2 ? (gfp)(a.x2 + ((size_t)b * a.c2 - a.c1) * HW) : xb1;
+    gfp gb1 = GATED == 1 ? (gfp)(a.gate1 + (size_t)b * a.c1 * HW) : nullptr;
+    gfp gb2 = (GATED == 1 && a.c2) ? (gfp)(a.gate2 + ((size_t)b * a.c2 - a.c1) * HW) : gb1;
+    asm volatile("" : "+s"(xb1), "+s"(xb2));
+    if constexpr (GATED == 1) asm volatile("" : "+s"(gb1), "+s"(gb2));
+    auto fetch_w_part = [&](int ci0, int k) {
+        int gi = (ci0 / HKC) * WU + tid + 256 * k;
+        gi = gi < wtotal ? gi : wtotal - 1;
+        const u32x4 t = wsrc[gi];
+        pw[k][0] = t[0]; pw[k][1] = t[1]; pw[k][2] = t[2]; pw[k][3] = t[3];
+    };
+    auto fetch_x_ch = [&](int ci0, int c) {
+        const int ci = ci0 + c;
+        const int cc = ci < cin ? ci : 0;
+        const bool first = cc < a.c1;
+        const gfp src = (first ? xb1 : xb2) + (size_t)cc * HW;
 #pragma unroll
-        for (int k = 0; k < WR; ++k) {
-            int gi = (ci0 / HKC) * WU + tid + 256 * k;
-            gi = gi < wtotal ? gi : wtotal - 1;
-            const u32x4 t = wsrc[gi];
-            pw[k][0] = t[0]; pw[k][1] = t[1]; pw[k][2] = t[2]; pw[k][3] = t[3];
+        for (int j = 0; j < NJ; ++j) px[c][j] = src[goff[j]];
+        if constexpr (GATED == 1) {
+            const gfp gsrc = (first ? gb1 : gb2) + (size_t)cc * HW;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) pg[c][j] = gsrc[goff[j]];
         }
-#pragma unroll
-        for (int c = 0; c < HKC; ++c) {
-            const int ci = ci0 + c;
-            const int cc = ci < cin ? ci : 0;
-            const bool first = cc < a.c1;
-            const size_t o = first ? ((size_t)b * a.c1 + cc) * HW : ((size_t)b * a.c2 + (cc - a.c1)) * HW;
-            const float* src = (first ? a.x1 : a.x2) + o;
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) px[c][j] = src[goff[j]];
-            if constexpr (GATED == 1) {
-                const float* gsrc = (first ? a.gate1 : a.gate2) + o;
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) pg[c][j] = gsrc[goff[j]];
-            }
-        }
+    };
+    auto fetch_mask = [&](int ci0) {
         if constexpr (GATED == 2) {
             const int w = (ci0 < cin ? ci0 : 0) >> 5;
             const unsigned* mrow = a.mask_in + ((size_t)b * mask_nw + w) * HW;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) pm[j] = mrow[goff[j]];
         }
+    };
+    auto fetch = [&](int ci0) {
+#pragma unroll
+        for (int k = 0; k < WR; ++k) fetch_w_part(ci0, k);
+#pragma unroll
+        for (int c = 0; c < HKC; ++c) fetch_x_ch(ci0, c);
+        fetch_mask(ci0);
+    };
+    // part `i` of `n` equal shares of a chunk's global loads (dealt out over MFMA taps: issued in one burst they fill
+    // the memory pipeline's queues and the wave waits ~50 cycles per load with its MFMAs stopped)
+    auto fetch_share = [&](int ci0, int i, int n) {
+#pragma unroll
+        for (int c = 0; c < HKC; ++c)
+            if (c * n / HKC == i) fetch_x_ch(ci0, c);
+#pragma unroll
+        for (int k = 0; k < WR; ++k)
+            if (k * n / WR == i) fetch_w_part(ci0, k);
+        if (i == n - 1) fetch_mask(ci0);
     };
     auto store = [&](int ci0, int buf) {
         u32x4* wl = smem16 + buf * STAGE;
@@ -205,40 +248,72 @@ __global__ void __launch_bounds__(256, 1) conv3x3_h16_kernel(const ConvKArgs a) 
             }
         }
     };
-    auto mfma_taps = [&](int buf, auto t0c, auto t1c) {
+    // MFMA over taps [T0, T1) of the chunk staged in LDS buffer `buf`.  The operands of tap t+1 are read while tap t's
+    // CT*PT MFMAs run (one wave per SIMD: nothing else covers the LDS latency); after_tap(t) is where the caller deals
+    // out its global loads.
+    auto mfma_taps = [&](int buf, auto t0c, auto t1c, auto&& after_tap) {
         const u32x4* wl = smem16 + buf * STAGE;
         const u32x4* xl = wl + WR * 256;
         constexpr int T0 = decltype(t0c)::value, T1 = decltype(t1c)::value;
+        constexpr bool AHEAD = NJ <= 4 && WPS == 1;    // (no registers for it with the 6-slot halo map or two waves per SIMD)
+        u32x4 av[AHEAD ? 2 : 1][CT], bv[AHEAD ? 2 : 1][PT];
+        auto load_ops = [&](int tap) {
+            const int toff = (tap / 3) * ROWPL + (tap % 3);
+            const int s = AHEAD ? tap & 1 : 0;
+#pragma unroll
+            for (int m = 0; m < CT; ++m) av[s][m] = wl[((tap * 2 + lh) * CT + m) * 32 + l31];
+#pragma unroll
+            for (int n = 0; n < PT; ++n) bv[s][n] = xl[baddr[n] + toff];
+        };
+        if constexpr (AHEAD) load_ops(T0);
 #pragma unroll
         for (int tap = T0; tap < T1; ++tap) {
-            const int toff = (tap / 3) * ROWPL + (tap % 3);
-            u32x4 av[CT], bv[PT];
-#pragma unroll
-            for (int m = 0; m < CT; ++m) av[m] = wl[((tap * 2 + lh) * CT + m) * 32 + l31];
-#pragma unroll
-            for (int n = 0; n < PT; ++n) bv[n] = xl[baddr[n] + toff];
+            if constexpr (AHEAD) {
+                if (tap + 1 < T1) load_ops(tap + 1);
+            } else {
+                load_ops(tap);
+            }
+            const int s = AHEAD ? tap & 1 : 0;
 #pragma unroll
             for (int m = 0; m < CT; ++m)
 #pragma unroll
-                for (int n = 0; n < PT; ++n) acc[m][n] = mfma_h16<PREC>(av[m], bv[n], acc[m][n]);
+                for (int n = 0; n < PT; ++n) acc[m][n] = mfma_h16<PREC>(av[s][m], bv[s][n], acc[m][n]);
+            after_tap(tap);
         }
     };
+    auto no_hook = [](int) {};
     using I0 = std::integral_constant<int, 0>;
     using I4 = std::integral_constant<int, 4>;
     using I9 = std::integral_constant<int, 9>;
 
+#ifdef H16_TIMING
+    unsigned long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t_last = clock64();
+#endif
     if constexpr (DB) {
         fetch(0);
         store(0, 0);
         if (HKC < cin) fetch(HKC);
         __syncthreads();
+        H16_TICK(0);
         int cur = 0;
         for (int ci0 = 0; ci0 < cin; ci0 += HKC) {
-            mfma_taps(cur, I0{}, I4{});
+            mfma_taps(cur, I0{}, I4{}, no_hook);
+            H16_TICK(1);
             if (ci0 + HKC < cin) store(ci0 + HKC, cur ^ 1);
-            if (ci0 + 2 * HKC < cin) fetch(ci0 + 2 * HKC);
-            mfma_taps(cur, I4{}, I9{});
+            H16_TICK(2);
+            // the staging registers are free again: chunk + 2, a share per tap.  Past the last chunk the loads re-read
+            // it (unconditional: under a branch the compiler waits for them on the spot to merge the registers)
+            if constexpr (NJ <= 4) {
+                const int cnext = ci0 + 2 * HKC < cin ? ci0 + 2 * HKC : ci0;
+                mfma_taps(cur, I4{}, I9{}, [&](int tap) { fetch_share(cnext, tap - 4, 5); });
+            } else {                                        // 128-wide frames: no registers to spare, one burst
+                if (ci0 + 2 * HKC < cin) fetch(ci0 + 2 * HKC);
+                mfma_taps(cur, I4{}, I9{}, no_hook);
+            }
+            H16_TICK(3);
             __syncthreads();
+            H16_TICK(4);
             cur ^= 1;
         }
     } else {
@@ -247,8 +322,13 @@ __global__ void __launch_bounds__(256, 1) conv3x3_h16_kernel(const ConvKArgs a) 
             __syncthreads();
             store(ci0, 0);
             __syncthreads();
-            if (ci0 + HKC < cin) fetch(ci0 + HKC);
-            mfma_taps(0, I0{}, I9{});
+            if constexpr (NJ <= 4) {
+                const int cnext = ci0 + HKC < cin ? ci0 + HKC : ci0;   // (unconditional loads, as above)
+                mfma_taps(0, I0{}, I9{}, [&](int tap) { fetch_share(cnext, tap, 9); });
+            } else {
+                if (ci0 + HKC < cin) fetch(ci0 + HKC);
+                mfma_taps(0, I0{}, I9{}, no_hook);
+            }
         }
     }
 
@@ -282,12 +362,15 @@ __global__ void __launch_bounds__(256, 1) conv3x3_h16_kernel(const ConvKArgs a) 
     for (int m = 0; m < CT; ++m) {
         // accumulate_y1: the values already in y1, ALL requested before anything waits on one of them (one
         // load-add-store per row in turn costs a memory round trip each: +200 us on a 128 -> 128 input gradient)
-        f32x4 old[16];
+        constexpr int Q4 = NPW / 4;                 // float4s per channel row of the slab
+        constexpr int RP = 64 / Q4;                 // rows per wave instruction
+        const int q4 = lane % Q4, rsub = lane / Q4;
+        f32x4 old[32 / RP];
         if (a.acc_y1 && vec) {
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int co = cg * CW + m * 32 + 2 * k + lh;
-                const int p = p0 + wave * NPW + 4 * l31;
+            for (int k = 0; k < 32 / RP; ++k) {
+                const int co = cg * CW + m * 32 + RP * k + rsub;
+                const int p = p0 + wave * NPW + 4 * q4;
                 const bool take = co < a.co1 && co < a.cout && p + 3 < HW;
                 const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
                 old[k] = take ? *reinterpret_cast<const f32x4*>(a.y1 + ((size_t)b * a.co1 + co) * HW + p) : zero;
@@ -311,11 +394,11 @@ __global__ void __launch_bounds__(256, 1) conv3x3_h16_kernel(const ConvKArgs a) 
         __syncthreads();
         unsigned bits[4] = {0u, 0u, 0u, 0u};        // sign bits of this lane's rows, per pixel of its float4
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int row = 2 * k + lh;
+        for (int k = 0; k < 32 / RP; ++k) {
+            const int row = RP * k + rsub;
             const int co = cg * CW + m * 32 + row;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(ep + row * EP + 4 * l31);
-            const int p = p0 + wave * NPW + 4 * l31;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(ep + row * EP + 4 * q4);
+            const int p = p0 + wave * NPW + 4 * q4;
 #pragma unroll
             for (int i = 0; i < 4; ++i) bits[i] |= (v[i] > 0.f ? 1u : 0u) << row;
             if (co < a.cout) {
@@ -334,11 +417,14 @@ __global__ void __launch_bounds__(256, 1) conv3x3_h16_kernel(const ConvKArgs a) 
             }
         }
         if (a.mask_out) {                           // wave-uniform: the 1-bit leaky-relu gate of these 32 channels
-            const int p = p0 + wave * NPW + 4 * l31;
+            const int p = p0 + wave * NPW + 4 * q4;
             const int nw = (a.cout + 31) >> 5, w = cg * CT + m;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) bits[i] |= __shfl_xor(bits[i], 32);
-            if (lh == 0 && w < nw) {
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int o = Q4; o < 64; o <<= 1) bits[i] |= __shfl_xor(bits[i], o);
+            }
+            if (lane < Q4 && w < nw) {
                 unsigned* dst = a.mask_out + ((size_t)b * nw + w) * HW + p;
                 if (vec && p + 3 < HW) {
                     u32x4 t;
@@ -353,6 +439,11 @@ __global__ void __launch_bounds__(256, 1) conv3x3_h16_kernel(const ConvKArgs a) 
         }
         if (m + 1 < CT) __syncthreads();
     }
+    H16_TICK(5);
+#ifdef H16_TIMING
+    if (blockIdx.x == H16_TIMING && blockIdx.y == 0 && tid == 0)
+        for (int i = 0; i < 8; ++i) h16_ticks[i] = t_acc[i];
+#endif
 }
 
 // ------------------------------------------------------------------ pack
@@ -431,15 +522,15 @@ extern "C" int scm_pack_conv3x3_weights_h16(const float* w, int cin, int cout, i
 }
 
 // ------------------------------------------------------------------ launch
-template <int PREC, int CT, int NJ, int GATED>
+template <int PREC, int CT, int PT, int NJ, int GATED, int WPS>
 static int launch_h16_nj(const ConvKArgs& a, int groups, hipStream_t s) {
     constexpr int WR = (9 * 2 * CT * 32 + 255) / 256;
     constexpr size_t stage = ((size_t)WR * 256 + 2 * NJ * 256) * 16;
-    constexpr size_t ep_bytes = 4 * 32 * (128 + 4) * sizeof(float);      // epilogue transpose slabs
-    constexpr size_t lds_main = 2 * stage <= 160 * 1024 ? 2 * stage : stage;
+    constexpr size_t ep_bytes = 4 * 32 * (PT * 32 + 4) * sizeof(float);   // epilogue transpose slabs
+    constexpr size_t lds_main = (WPS == 1 && 2 * stage <= 160 * 1024) ? 2 * stage : stage;
     constexpr size_t lds = (lds_main > ep_bytes ? lds_main : ep_bytes) + CT * 32 * sizeof(float);   // + bias table
-    static_assert(lds <= 160 * 1024, "halo tile exceeds the LDS");
-    auto kern = conv3x3_h16_kernel<PREC, CT, 4, NJ, GATED>;
+    static_assert(lds * WPS <= 160 * 1024, "halo tile exceeds the LDS");
+    auto kern = conv3x3_h16_kernel<PREC, CT, PT, NJ, GATED, WPS>;
     static std::atomic<uint64_t> attr_done{0};       // per (instantiation, device)
     if (int rc = scm_ensure_lds_attr(reinterpret_cast<const void*>(kern), attr_done, 160 * 1024)) return rc;
     hipLaunchKernelGGL(kern, dim3(a.B * a.tiles_per_img, groups), dim3(256), lds, s, a);
@@ -447,25 +538,33 @@ static int launch_h16_nj(const ConvKArgs& a, int groups, hipStream_t s) {
     return SCM_OK;
 }
 
-template <int PREC, int CT, int NJ>
+template <int PREC, int CT, int PT, int NJ, int WPS>
 static int launch_h16_g(const ConvKArgs& a, int groups, hipStream_t s) {
-    if (a.gate_act == 0) return launch_h16_nj<PREC, CT, NJ, 0>(a, groups, s);
-    if (a.mask_in && a.gate_act == SCM_ACT_LRELU && a.c2 == 0) return launch_h16_nj<PREC, CT, NJ, 2>(a, groups, s);
-    return launch_h16_nj<PREC, CT, NJ, 1>(a, groups, s);
+    if (a.gate_act == 0) return launch_h16_nj<PREC, CT, PT, NJ, 0, WPS>(a, groups, s);
+    if (a.mask_in && a.gate_act == SCM_ACT_LRELU && a.c2 == 0) return launch_h16_nj<PREC, CT, PT, NJ, 2, WPS>(a, groups, s);
+    return launch_h16_nj<PREC, CT, PT, NJ, 1, WPS>(a, groups, s);
 }
 
-template <int PREC, int CT>
-static int launch_h16(const ConvKArgs& k, int groups, hipStream_t s) {
-    constexpr int NP = 512;
-    ConvKArgs a = k;
+static void h16_tile_geometry(ConvKArgs& a, int NP) {
     const int HW = a.H * a.W;
     a.tiles_per_img = (HW + NP - 1) / NP;
     int rows = (NP % a.W == 0) ? NP / a.W : (NP + a.W - 2) / a.W + 1;
     if (rows > a.H) rows = a.H;
     a.plane = (rows + 2) * (a.W + 2);
-    if (a.plane <= 3 * 256) return launch_h16_g<PREC, CT, 3>(a, groups, s);
-    if (a.plane <= 4 * 256) return launch_h16_g<PREC, CT, 4>(a, groups, s);
-    if (a.plane <= 6 * 256) return launch_h16_g<PREC, CT, 6>(a, groups, s);
+}
+
+template <int PREC, int CT>
+static int launch_h16(const ConvKArgs& k, int groups, hipStream_t s) {
+    ConvKArgs a = k;
+    if constexpr (CT == 4) {
+        // 128 output channels: two 256-pixel workgroups per CU (see WPS) when the halo tile fits two slots per thread
+        h16_tile_geometry(a, 256);
+        if (a.plane <= 2 * 256 && !getenv("SCM_H16_ONE_WG")) return launch_h16_g<PREC, CT, 2, 2, 2>(a, groups, s);
+    }
+    h16_tile_geometry(a, 512);
+    if (a.plane <= 3 * 256) return launch_h16_g<PREC, CT, 4, 3, 1>(a, groups, s);
+    if (a.plane <= 4 * 256) return launch_h16_g<PREC, CT, 4, 4, 1>(a, groups, s);
+    if (a.plane <= 6 * 256) return launch_h16_g<PREC, CT, 4, 6, 1>(a, groups, s);
     scm_set_error("scm_conv3x3_h16: image width %d too large for the halo staging map", a.W);
     return SCM_EUNSUPPORTED;
 }

@@ -173,19 +173,37 @@ __global__ void __launch_bounds__(256 * WN, 1) conv3x3_wgrad_h16_kernel(const Wg
             px[9] = row[cr];
             // the pixel one past the segment (the kx = 2 tap of its last pixel): wherever it falls in this thread's
             // ten, it is the wrapped column under circular padding -- load8 clamps instead of wrapping
-            int ce = x0 + ps;
-            if (circ) ce = ce >= W ? ce - W : ce;
-            pe = row[ce < W ? ce : W - 1];
+            if constexpr (!VEC) {
+                int ce = x0 + ps;
+                if (circ) ce = ce >= W ? ce - W : ce;
+                pe = row[ce < W ? ce : W - 1];
+            }
         };
+        // VEC kernels (W == nseg * PS, PS % 8 == 0): an 8-pixel group lies wholly inside or wholly outside the segment,
+        // and the pixel one past the segment is px[9] of its last group (fetch_x wraps / clamps it).  Validity is then
+        // three per-thread bit masks (whole group, left halo pixel, right halo pixel) and one wave-uniform row mask:
+        // no per-pixel branches or selects.
+        const unsigned xm_all = (xvalid && 8 * xg < ps) ? ~0u : 0u;
+        const unsigned xm_l = (circ || xc0 > 0) ? xm_all : 0u;
+        const unsigned xm_r = (circ || xc0 + 8 < W) ? xm_all : 0u;
         auto store_x = [&](int r) {
-            bool rok = xvalid;
-            if (!circ) rok = rok && r >= 0 && r < H;
             float v[10];
+            if constexpr (VEC) {
+                const unsigned rowm = (circ || (r >= 0 && r < H)) ? ~0u : 0u;
+                const unsigned ma = xm_all & rowm;
+                v[0] = __uint_as_float(__float_as_uint(px[0]) & (xm_l & rowm));
 #pragma unroll
-            for (int i = 0; i < 10; ++i) {
-                const int c = xc0 - 1 + i;        // image column (before wrapping)
-                const bool ok = rok && (circ || (c >= 0 && c < W)) && (c < x0 + ps + 1);
-                v[i] = ok ? (c == x0 + ps ? pe : px[i]) : 0.f;
+                for (int i = 1; i < 9; ++i) v[i] = __uint_as_float(__float_as_uint(px[i]) & ma);
+                v[9] = __uint_as_float(__float_as_uint(px[9]) & (xm_r & rowm));
+            } else {
+                bool rok = xvalid;
+                if (!circ) rok = rok && r >= 0 && r < H;
+#pragma unroll
+                for (int i = 0; i < 10; ++i) {
+                    const int c = xc0 - 1 + i;        // image column (before wrapping)
+                    const bool ok = rok && (circ || (c >= 0 && c < W)) && (c < x0 + ps + 1);
+                    v[i] = ok ? (c == x0 + ps ? pe : px[i]) : 0.f;
+                }
             }
             u32x4* slot = xs + ((r + 1) & 3) * WG_XSLOT + xg * WG_XP + xc;
             const unsigned m12 = wpack2<PREC>(v[1], v[2]), m34 = wpack2<PREC>(v[3], v[4]);
@@ -204,21 +222,27 @@ __global__ void __launch_bounds__(256 * WN, 1) conv3x3_wgrad_h16_kernel(const Wg
 #pragma unroll
             for (int j = 0; j < DT; ++j) {
                 load8(dsrc[j] + (size_t)y * W, dc0, pd[j]);
-                load8(gsrc[j] + (size_t)y * W, dc0, pgv[j]);
+                if (gated) load8(gsrc[j] + (size_t)y * W, dc0, pgv[j]);
             }
         };
-        auto store_d = [&](int y) {
+        unsigned dm[DT];
+#pragma unroll
+        for (int j = 0; j < DT; ++j) dm[j] = (dvalid[j] && 8 * dg < ps) ? ~0u : 0u;
+        // MODE 0: dyp = dy; 1: dy * act'(gate tensor); 2: dy * leaky-relu slope from the 1-bit gate mask.  One branch per
+        // row on the (wave-uniform) mode, none per element.
+        auto store_d_mode = [&](int y, auto modec) {
+            constexpr int MODE = decltype(modec)::value;
 #pragma unroll
             for (int j = 0; j < DT; ++j) {
                 float v[8];
                 float s = 0.f;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    const int c = dc0 + i;
                     float t = pd[j][i];
-                    if (use_mask) t *= ((__float_as_uint(pgv[j][i]) >> dbit[j]) & 1u) ? 1.f : 0.01f;
-                    else if (gated) t *= scm_act_grad_from_out(pgv[j][i], gate_act);
-                    v[i] = (dvalid[j] && c < x0 + ps) ? t : 0.f;
+                    if constexpr (MODE == 2) t *= ((__float_as_uint(pgv[j][i]) >> dbit[j]) & 1u) ? 1.f : 0.01f;
+                    if constexpr (MODE == 1) t *= scm_act_grad_from_out(pgv[j][i], gate_act);
+                    if constexpr (VEC) v[i] = __uint_as_float(__float_as_uint(t) & dm[j]);
+                    else v[i] = (dvalid[j] && dc0 + i < x0 + ps) ? t : 0.f;
                     s += v[i];
                 }
                 csum[j] += s;
@@ -227,6 +251,11 @@ __global__ void __launch_bounds__(256 * WN, 1) conv3x3_wgrad_h16_kernel(const Wg
                 u[2] = wpack2<PREC>(v[4], v[5]); u[3] = wpack2<PREC>(v[6], v[7]);
                 dsm[(y & 1) * WG_DSTAGE + dg * WG_DP + (tid >> 3) + DSTEP * j] = u;
             }
+        };
+        auto store_d = [&](int y) {
+            if (use_mask) store_d_mode(y, std::integral_constant<int, 2>{});
+            else if (gated) store_d_mode(y, std::integral_constant<int, 1>{});
+            else store_d_mode(y, std::integral_constant<int, 0>{});
         };
 
         // prologue: x rows y_begin-1 and y_begin
@@ -245,10 +274,11 @@ __global__ void __launch_bounds__(256 * WN, 1) conv3x3_wgrad_h16_kernel(const Wg
             store_x(y + 1);
             store_d(y);
             __syncthreads();
-            if (y + 1 < y_end) {
-                fetch_x(y + 2);
-                fetch_d(y + 1);
-            }
+            // the next row's loads, in flight under this row's MFMAs; after the last row they re-read it (unconditional:
+            // under a branch the compiler waits for the loads on the spot to merge the registers)
+            const bool more = y + 1 < y_end;
+            fetch_x(more ? y + 2 : y + 1);
+            fetch_d(more ? y + 1 : y);
             const u32x4* dst = dsm + (y & 1) * WG_DSTAGE + wm * 32 + l31;
             for (int ks = 0; ks < nks; ++ks) {
                 const int g = 2 * ks + lh;
@@ -303,7 +333,7 @@ int scm_launch_wgrad_h16(const WgradKArgs& a, const WgradPlan& p, int precision,
         scm_set_error("scm_conv3x3_wgrad_h16: row segment of %d pixels (W = %d) unsupported", a.PS, a.W);
         return SCM_EUNSUPPORTED;
     }
-    const bool vec = (a.W % 4 == 0) && (a.PS % 8 == 0) &&
+    const bool vec = (a.W % 4 == 0) && (a.PS % 8 == 0) && (a.W == a.nseg * a.PS) &&
                      ((reinterpret_cast<size_t>(a.x1) | reinterpret_cast<size_t>(a.x2) | reinterpret_cast<size_t>(a.dy) |
                        reinterpret_cast<size_t>(a.gate) | reinterpret_cast<size_t>(a.gate_mask)) % 16 == 0);
     const bool narrow = p.ci_groups == 1 && a.c1 + a.c2 <= 32;      // one ci tile: 4 waves

@@ -311,19 +311,19 @@ __global__ void __launch_bounds__(256, 1) conv3x3_x3_kernel(const ConvKArgs a) {
             __syncthreads();
             X3_TICK(1);
         }
-        const bool more = ci0 + XKC < cin;
+        // Past the last chunk the loads re-read it: unconditional, because under a branch the compiler waits for the
+        // loads on the spot to merge the registers.
+        const int cnext = ci0 + XKC < cin ? ci0 + XKC : ci0;
         X3_TICK(5);
         mfma_half(NH - 1, [&](int tap) {    // the next chunk's pixels and first weight half
-            if (more) {
-                constexpr int CPT = XKC / 8, WPT = (3 * WR + 7) / 8;
-                if (tap < 8) {
+            constexpr int CPT = XKC / 8, WPT = (3 * WR + 7) / 8;
+            if (tap < 8) {
 #pragma unroll
-                    for (int c = tap * CPT; c < (tap + 1) * CPT; ++c) fetch_x_ch(ci0 + XKC, c);
+                for (int c = tap * CPT; c < (tap + 1) * CPT; ++c) fetch_x_ch(cnext, c);
 #pragma unroll
-                    for (int i = tap * WPT; i < (tap + 1) * WPT && i < 3 * WR; ++i) fetch_w_part(ci0 + XKC, 0, i);
-                } else {
-                    fetch_mask(ci0 + XKC);
-                }
+                for (int i = tap * WPT; i < (tap + 1) * WPT && i < 3 * WR; ++i) fetch_w_part(cnext, 0, i);
+            } else {
+                fetch_mask(cnext);
             }
         });
         X3_TICK(6);
