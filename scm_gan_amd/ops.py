@@ -121,10 +121,14 @@ def pack_conv3x3(weight, cin, cout, transposed=False, cin_total=0, ci0=0):
     return fp, dp, PREC_F32, PREC_F32
 
 
-def x3_serves(H, W):
-    """scm_conv3x3_x3 stages the halo tile of 512 pixels in 768 slots per channel."""
+def x3_serves(H, W, B=None):
+    """scm_conv3x3_x3 stages the halo tile of 512 pixels in 768 slots per channel.  With a batch size: also whether
+    the launch fills at least half of the 256 CUs with its 512-pixel workgroups -- below that (configs[0], the planner's
+    beams) the native kernel's 128-pixel tiles are faster (3 638 vs 3 233 frames/s at batch 8, horizon 5)."""
     rows = 512 // W if 512 % W == 0 else (512 + W - 2) // W + 1
-    return (min(rows, H) + 2) * (W + 2) <= 768
+    if (min(rows, H) + 2) * (W + 2) > 768:
+        return False
+    return B is None or B * ((H * W + 511) // 512) >= 128
 
 
 class KernelTimer(object):
@@ -288,7 +292,7 @@ class Conv3x3Fn(Function):
         cout = w.shape[1] if cfg["transposed"] else w.shape[0]
         cin_total = w.shape[0] if cfg["transposed"] else w.shape[1]
         fpack, dpack, fprec, dprec = cfg["packs"][:4]
-        if (fprec == PREC_BF16X3 or dprec == PREC_BF16X3) and not x3_serves(H, W):
+        if (fprec == PREC_BF16X3 or dprec == PREC_BF16X3) and not x3_serves(H, W, B):
             fpack, dpack, fprec, dprec = cfg["packs"][4], cfg["packs"][5], PREC_F32, PREC_F32
         sbias = None
         if act_vec is not None:
@@ -360,7 +364,8 @@ class Conv3x3Fn(Function):
                             cin_total, 0, _p(w) if dot_part is not None else None, _p(dot_part), _p(ctx.mask))
             wprec = ctx.dprec
             if compute_precision() == "fp32x3":
-                # the split kernel takes 128-wide weight gradients of layers with more than 16 input channels
+                # the split kernel takes 128-wide weight gradients of layers with more than 16 input channels (at any batch:
+                # its work split fills the chip also where the forward's 512-pixel tiles do not)
                 wprec = PREC_BF16X3 if (W >= 8 and x3_serves(H, W) and cout > 64 and c1 + c2 > 16) else PREC_F32
             if wprec:
                 L.check(lib.scm_conv3x3_wgrad_h16(ctypes.byref(d), wprec, _stream()), "scm_conv3x3_wgrad_h16")
