@@ -230,9 +230,10 @@ def measured_traffic(kernel_name):
     the kernel it was measured on: each file records the sha of the kernel's source file, and a
     file whose sha no longer matches the tree is skipped -> traffic null rather than stale."""
     import glob
-    src = {"h16": "conv3x3_h16.hip", "mfma": "conv3x3_mfma.hip"}["h16" if "h16" in kernel_name else "mfma"]
+    kind = "h16" if "h16" in kernel_name else ("x3" if "x3_kernel" in kernel_name else "mfma")
+    src = {"h16": "conv3x3_h16.hip", "x3": "conv3x3_x3.hip", "mfma": "conv3x3_mfma.hip"}[kind]
     sha = _sha16(os.path.join(ROOT, "scm_gan_amd", "csrc", src))
-    want = "conv3x3_h16_kernel<1," if "h16" in kernel_name else "conv3x3_mfma_kernel<4, 2, 2, 0,"
+    want = {"h16": "conv3x3_h16_kernel<1,", "x3": "conv3x3_x3_kernel<2, 2, 0>", "mfma": "conv3x3_mfma_kernel<4, 2, 2, 0,"}[kind]
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_pmc*.json")), reverse=True):
         try:
             pmc = json.load(open(f))
@@ -395,12 +396,15 @@ def main():
             # HBM bytes per launch: a PMC measurement (separate rocprofv3 --pmc passes, tools/prof_hot2.py) cited
             # from profiles/, valid only while the kernel's source is the one it was measured on (else null)
             tr_info = measured_traffic(name)
-            peak = PEAK_F16_MFMA_TFLOPS if "h16" in name else (PEAK_F16_MFMA_TFLOPS / 6.0 if "x3" in name else PEAK_F32_MFMA_TFLOPS)
+            # (the split kernels spend six bf16 MFMA products per fp32 product: their roof in fp32 FLOP is the bf16 peak / 6)
+            peak = PEAK_F16_MFMA_TFLOPS if "h16" in name else (PEAK_F16_MFMA_TFLOPS / 6.0 if "x3_kernel" in name
+                                                             else PEAK_F32_MFMA_TFLOPS)
             out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": peak,
                                "unit": "TFLOP/s", "frac": achieved / peak,
                                "traffic": tr_info["bytes"] if tr_info else None, "traffic_source": tr_info,
                                "launches": s["launches"], "avg_launch_us": s["ms"] * 1e3 / s["launches"],
-                               "share_of_step": s["ms"] / (dt * 1e3)}
+                               # brackets are recorded on every 5th timed step: scale to the whole timed region
+                               "share_of_step": s["ms"] / (dt * 1e3) * a.steps / len(range(0, a.steps, 5))}
             out["kernels"] = {k: {"launches": v["launches"], "ms_total": round(v["ms"], 3),
                                   "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12} for k, v in summ.items()}
         if world == 1 and not a.profile_mode and a.precision == "fp32" and a.size <= 64:

@@ -128,7 +128,9 @@ def x3_serves(H, W, B=None):
     rows = 512 // W if 512 % W == 0 else (512 + W - 2) // W + 1
     if (min(rows, H) + 2) * (W + 2) > 768:
         return False
-    return B is None or B * ((H * W + 511) // 512) >= 128
+    if B is None or os.environ.get("SCM_X3_ANY_BATCH"):      # (the parity suite runs its small batches through the split kernels)
+        return True
+    return B * ((H * W + 511) // 512) >= 128
 
 
 class KernelTimer(object):
