@@ -56,10 +56,11 @@ __device__ unsigned long long x3_ticks[8];
 
 // GATED: 0 plain input, 1 input * act'(gate tensor), 2 input * leaky-relu slope from the 1-bit gate mask
 // CT: 32-channel row tiles per weight half (1 or 2); NH: halves per workgroup (1 or 2)
-template <int CT, int NH, int GATED>
+// PT: 32-pixel tiles per wave (4: 512-pixel workgroups; 1: 128-pixel workgroups for launches that would leave CUs idle)
+// NJ: halo-tile slots per thread and channel (256 * NJ staged elements)
+template <int CT, int NH, int GATED, int PT = X3_PT, int NJ = X3_NJ>
 __global__ void __launch_bounds__(256, 1) conv3x3_x3_kernel(const ConvKArgs a) {
     extern __shared__ __attribute__((aligned(16))) u32x4x smx[];
-    constexpr int PT = X3_PT, NJ = X3_NJ;
     constexpr int CW = NH * CT * 32;               // output channels of a workgroup
     constexpr int WU = 9 * 2 * CT * 32;            // 16-byte units of one component of a weight chunk half: [tap][h][m][lane]
     constexpr int WR = (WU + 255) / 256;
@@ -351,12 +352,15 @@ __global__ void __launch_bounds__(256, 1) conv3x3_x3_kernel(const ConvKArgs a) {
     for (int m = 0; m < NH * CT; ++m) {
         // accumulate_y1: the values already in y1, ALL requested before anything waits on one of them (one
         // load-add-store per row in turn costs a memory round trip each: +200 us on a 128 -> 128 input gradient)
-        f32x4 old[16];
+        constexpr int Q4 = NPW / 4;                 // float4s per channel row of the slab
+        constexpr int RP = 64 / Q4;                 // rows per wave instruction
+        const int q4 = lane % Q4, rsub = lane / Q4;
+        f32x4 old[32 / RP];
         if (a.acc_y1 && vec) {
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int co = cg * CW + m * 32 + 2 * k + lh;
-                const int p = p0 + wave * NPW + 4 * l31;
+            for (int k = 0; k < 32 / RP; ++k) {
+                const int co = cg * CW + m * 32 + RP * k + rsub;
+                const int p = p0 + wave * NPW + 4 * q4;
                 const bool take = co < a.co1 && co < a.cout && p + 3 < HW;
                 const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
                 old[k] = take ? *reinterpret_cast<const f32x4*>(a.y1 + ((size_t)b * a.co1 + co) * HW + p) : zero;
@@ -380,11 +384,11 @@ __global__ void __launch_bounds__(256, 1) conv3x3_x3_kernel(const ConvKArgs a) {
         __syncthreads();
         unsigned bits[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int row = 2 * k + lh;
+        for (int k = 0; k < 32 / RP; ++k) {
+            const int row = RP * k + rsub;
             const int co = cg * CW + m * 32 + row;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(ep + row * EP + 4 * l31);
-            const int p = p0 + wave * NPW + 4 * l31;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(ep + row * EP + 4 * q4);
+            const int p = p0 + wave * NPW + 4 * q4;
 #pragma unroll
             for (int i = 0; i < 4; ++i) bits[i] |= (v[i] > 0.f ? 1u : 0u) << row;
 #ifdef X3_NOSTORE
@@ -407,11 +411,14 @@ __global__ void __launch_bounds__(256, 1) conv3x3_x3_kernel(const ConvKArgs a) {
             }
         }
         if (a.mask_out) {
-            const int p = p0 + wave * NPW + 4 * l31;
+            const int p = p0 + wave * NPW + 4 * q4;
             const int nw = (a.cout + 31) >> 5, w = cg * NH * CT + m;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) bits[i] |= __shfl_xor(bits[i], 32);
-            if (lh == 0 && w < nw) {
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int o = Q4; o < 64; o <<= 1) bits[i] |= __shfl_xor(bits[i], o);
+            }
+            if (lane < Q4 && w < nw) {
                 unsigned* dst = a.mask_out + ((size_t)b * nw + w) * HW + p;
                 if (vec && p + 3 < HW) {
                     u32x4x t;
@@ -507,25 +514,34 @@ extern "C" int scm_pack_conv3x3_weights_x3(const float* w, int cin, int cout, in
 }
 
 // ------------------------------------------------------------------ launch
-template <int CT, int NH, int GATED>
+template <int CT, int NH, int GATED, int PT, int NJ>
 static int launch_x3(const ConvKArgs& a, int groups, hipStream_t s) {
     constexpr int WR = (9 * 2 * CT * 32 + 255) / 256;
-    constexpr size_t stage = (size_t)3 * (WR * 256 + 2 * X3_NJ * 256) * 16;
-    constexpr size_t ep_bytes = 4 * 32 * (128 + 4) * sizeof(float);
+    constexpr size_t stage = (size_t)3 * (WR * 256 + 2 * NJ * 256) * 16;
+    constexpr size_t ep_bytes = 4 * 32 * (PT * 32 + 4) * sizeof(float);
     constexpr size_t lds = (stage > ep_bytes ? stage : ep_bytes) + NH * CT * 32 * sizeof(float);
     static_assert(lds <= 160 * 1024, "stage exceeds the LDS");
-    auto kern = conv3x3_x3_kernel<CT, NH, GATED>;
+    auto kern = conv3x3_x3_kernel<CT, NH, GATED, PT, NJ>;
     static std::atomic<uint64_t> attr_done{0};
     if (int rc = scm_ensure_lds_attr(reinterpret_cast<const void*>(kern), attr_done, 160 * 1024)) return rc;
     hipLaunchKernelGGL(kern, dim3(a.B * a.tiles_per_img, groups), dim3(256), lds, s, a);
     SCM_LAUNCH_CHECK("conv3x3_x3_kernel");
     return SCM_OK;
 }
-template <int CT, int NH>
+template <int CT, int NH, int PT, int NJ>
 static int launch_x3_g(const ConvKArgs& a, int groups, hipStream_t s) {
-    if (a.gate_act == 0) return launch_x3<CT, NH, 0>(a, groups, s);
-    if (a.mask_in && a.gate_act == SCM_ACT_LRELU && a.c2 == 0) return launch_x3<CT, NH, 2>(a, groups, s);
-    return launch_x3<CT, NH, 1>(a, groups, s);
+    if (a.gate_act == 0) return launch_x3<CT, NH, 0, PT, NJ>(a, groups, s);
+    if (a.mask_in && a.gate_act == SCM_ACT_LRELU && a.c2 == 0) return launch_x3<CT, NH, 2, PT, NJ>(a, groups, s);
+    return launch_x3<CT, NH, 1, PT, NJ>(a, groups, s);
+}
+// halo-tile geometry of NP-pixel workgroups; returns the elements per channel to stage
+static int x3_tile_geometry(ConvKArgs& k, int NP) {
+    const int HW = k.H * k.W;
+    k.tiles_per_img = (HW + NP - 1) / NP;
+    int rows = (NP % k.W == 0) ? NP / k.W : (NP + k.W - 2) / k.W + 1;
+    if (rows > k.H) rows = k.H;
+    k.plane = (rows + 2) * (k.W + 2);
+    return k.plane;
 }
 
 extern "C" int scm_conv3x3_x3(const scm_conv3x3_desc* d, void* stream) {
@@ -550,18 +566,21 @@ extern "C" int scm_conv3x3_x3(const scm_conv3x3_desc* d, void* stream) {
     k.mask_in = d->gate_mask_in;
     k.mask_out = (d->act == SCM_ACT_LRELU && d->cout > 32) ? d->gate_mask_out : nullptr;
     SCM_REQUIRE(!d->gate_mask_out || k.mask_out, "scm_conv3x3_x3: gate_mask_out needs act == LRELU and cout > 32");
-    const int HW = d->H * d->W, NP = 512;
-    k.tiles_per_img = (HW + NP - 1) / NP;
-    int rows = (NP % d->W == 0) ? NP / d->W : (NP + d->W - 2) / d->W + 1;
-    if (rows > d->H) rows = d->H;
-    k.plane = (rows + 2) * (d->W + 2);
-    if (k.plane > X3_NJ * 256) {
+    hipStream_t s = (hipStream_t)stream;
+    // 128 output channels in a launch whose 512-pixel workgroups would fill less than half of the 256 CUs (small batches:
+    // BASELINE configs[0], the planner's beams, the eval rollout): 128-pixel workgroups, four times as many
+    if (d->cout > 64) {
+        x3_tile_geometry(k, 512);
+        const int groups = (d->cout + 127) / 128;
+        if (d->B * k.tiles_per_img * groups < 128 && x3_tile_geometry(k, 128) <= 2 * 256)
+            return launch_x3_g<2, 2, 1, 2>(k, groups, s);
+    }
+    if (x3_tile_geometry(k, 512) > X3_NJ * 256) {
         scm_set_error("scm_conv3x3_x3: a 512-pixel halo tile of a %d-wide image (%d elements) exceeds the %d staged per channel",
                       d->W, k.plane, X3_NJ * 256);
         return SCM_EUNSUPPORTED;
     }
-    hipStream_t s = (hipStream_t)stream;
-    if (d->cout <= 32) return launch_x3_g<1, 1>(k, 1, s);
-    if (d->cout <= 64) return launch_x3_g<2, 1>(k, 1, s);
-    return launch_x3_g<2, 2>(k, (d->cout + 127) / 128, s);        // the pack is padded to whole 128-channel workgroups
+    if (d->cout <= 32) return launch_x3_g<1, 1, X3_PT, X3_NJ>(k, 1, s);
+    if (d->cout <= 64) return launch_x3_g<2, 1, X3_PT, X3_NJ>(k, 1, s);
+    return launch_x3_g<2, 2, X3_PT, X3_NJ>(k, (d->cout + 127) / 128, s);   // the pack is padded to whole 128-channel workgroups
 }

@@ -121,16 +121,24 @@ def pack_conv3x3(weight, cin, cout, transposed=False, cin_total=0, ci0=0):
     return fp, dp, PREC_F32, PREC_F32
 
 
-def x3_serves(H, W, B=None):
-    """scm_conv3x3_x3 stages the halo tile of 512 pixels in 768 slots per channel.  With a batch size: also whether
-    the launch fills at least half of the 256 CUs with its 512-pixel workgroups -- below that (configs[0], the planner's
-    beams) the native kernel's 128-pixel tiles are faster (3 638 vs 3 233 frames/s at batch 8, horizon 5)."""
-    rows = 512 // W if 512 % W == 0 else (512 + W - 2) // W + 1
-    if (min(rows, H) + 2) * (W + 2) > 768:
+def _halo_plane(H, W, NP):
+    rows = NP // W if NP % W == 0 else (NP + W - 2) // W + 1
+    return (min(rows, H) + 2) * (W + 2)
+
+
+def x3_serves(H, W, B=None, cout=None):
+    """Whether scm_conv3x3_x3 takes this launch: its 512-pixel workgroups stage the halo tile in 768 slots per channel.
+    With a batch size: a launch that fills less than half of the 256 CUs with 512-pixel workgroups (configs[0], the
+    planner's beams, the eval rollout) is taken only where the kernel has its 128-pixel form (more than 64 output
+    channels, halo tile within 512 slots); thinner layers then stay on the native kernel's small tiles."""
+    if _halo_plane(H, W, 512) > 768:
         return False
     if B is None or os.environ.get("SCM_X3_ANY_BATCH"):      # (the parity suite runs its small batches through the split kernels)
         return True
-    return B * ((H * W + 511) // 512) >= 128
+    groups = 1 if cout is None else (cout + 127) // 128
+    if B * ((H * W + 511) // 512) * groups >= 128:
+        return True
+    return cout is not None and cout > 64 and _halo_plane(H, W, 128) <= 512
 
 
 class KernelTimer(object):
@@ -294,8 +302,10 @@ class Conv3x3Fn(Function):
         cout = w.shape[1] if cfg["transposed"] else w.shape[0]
         cin_total = w.shape[0] if cfg["transposed"] else w.shape[1]
         fpack, dpack, fprec, dprec = cfg["packs"][:4]
-        if (fprec == PREC_BF16X3 or dprec == PREC_BF16X3) and not x3_serves(H, W, B):
-            fpack, dpack, fprec, dprec = cfg["packs"][4], cfg["packs"][5], PREC_F32, PREC_F32
+        if fprec == PREC_BF16X3 and not x3_serves(H, W, B, cout):
+            fpack, fprec = cfg["packs"][4], PREC_F32
+        if dprec == PREC_BF16X3 and not x3_serves(H, W, B, c1 + c2):
+            dpack, dprec = cfg["packs"][5], PREC_F32
         sbias = None
         if act_vec is not None:
             A = act_vec.shape[1]

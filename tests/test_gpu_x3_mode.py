@@ -32,7 +32,10 @@ def _err(a, ref):
 
 
 @pytest.mark.parametrize("B,cin,cout,H,W,circ", [(2, 16, 128, 16, 16, 1), (1, 128, 128, 20, 12, 1), (2, 256, 128, 16, 16, 1),
-                                                  (1, 9, 128, 33, 20, 0), (1, 128, 256, 7, 13, 1), (3, 128, 64, 64, 64, 1)])
+                                                  (1, 9, 128, 33, 20, 0), (1, 128, 256, 7, 13, 1), (3, 128, 64, 64, 64, 1),
+                                                  # 128 workgroups of 512 pixels: the large-tile form of the 128-channel
+                                                  # kernel (the small batches above run its 128-pixel form)
+                                                  (16, 32, 128, 64, 64, 1)])
 def test_split_kernels_match_float64_like_the_native_ones(x3, B, cin, cout, H, W, circ):
     ops = x3
     from scm_gan_amd import _lib as L
