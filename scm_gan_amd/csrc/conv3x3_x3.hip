@@ -15,6 +15,7 @@
 //     fetched and split once per 128 output channels, 135 KB of LDS in all.
 #include "conv_args.h"
 #include <type_traits>
+#include <stdlib.h>
 
 #define XKC 16
 #define X3_CT 2
@@ -567,12 +568,15 @@ extern "C" int scm_conv3x3_x3(const scm_conv3x3_desc* d, void* stream) {
     k.mask_out = (d->act == SCM_ACT_LRELU && d->cout > 32) ? d->gate_mask_out : nullptr;
     SCM_REQUIRE(!d->gate_mask_out || k.mask_out, "scm_conv3x3_x3: gate_mask_out needs act == LRELU and cout > 32");
     hipStream_t s = (hipStream_t)stream;
-    // 128 output channels in a launch whose 512-pixel workgroups would fill less than half of the 256 CUs (small batches:
-    // BASELINE configs[0], the planner's beams, the eval rollout): 128-pixel workgroups, four times as many
+    // 128 output channels in a launch of fewer than 160 512-pixel workgroups on the 256 CUs (small batches: BASELINE
+    // configs[0], the planner's beams, the eval rollout): 128-pixel workgroups, four times as many.  Measured on the
+    // B x 64 x 64, horizon-5 iteration: B = 16 (128 workgroups) 5 993 vs 5 672 frames/s in favour of the small form,
+    // B = 24 (192) 6 236 vs 6 586 and B = 32 (256) 7 388 vs 8 257 against it.
     if (d->cout > 64) {
         x3_tile_geometry(k, 512);
         const int groups = (d->cout + 127) / 128;
-        if (d->B * k.tiles_per_img * groups < 128 && x3_tile_geometry(k, 128) <= 2 * 256)
+        static const int small_below = getenv("SCM_X3_SMALL_BELOW") ? atoi(getenv("SCM_X3_SMALL_BELOW")) : 160;
+        if (d->B * k.tiles_per_img * groups < small_below && x3_tile_geometry(k, 128) <= 2 * 256)
             return launch_x3_g<2, 2, 1, 2>(k, groups, s);
     }
     if (x3_tile_geometry(k, 512) > X3_NJ * 256) {
