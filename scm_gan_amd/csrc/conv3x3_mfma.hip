@@ -130,6 +130,16 @@ __global__ void __launch_bounds__(256, WPS) conv3x3_mfma_kernel(const ConvKArgs 
     unsigned pm[GATED == 2 ? NJ : 1];
     const int mask_nw = (a.c1 + 31) >> 5;
 
+    // per-image bases of the two concatenated inputs, indexed by the CONCATENATED channel; pinned in SGPRs (left to
+    // itself the compiler selects between the kernarg slots and re-loads the pointer, with a wait, per channel) and
+    // spelled out as global address space (behind the asm it would otherwise fall back to flat loads)
+    typedef const __attribute__((address_space(1))) float* gfp;
+    gfp xb1 = (gfp)(a.x1 + (size_t)b * a.c1 * HW);
+    gfp xb2 = a.c2 ? (gfp)(a.x2 + ((size_t)b * a.c2 - a.c1) * HW) : xb1;
+    gfp gb1 = GATED == 1 ? (gfp)(a.gate1 + (size_t)b * a.c1 * HW) : nullptr;
+    gfp gb2 = (GATED == 1 && a.c2) ? (gfp)(a.gate2 + ((size_t)b * a.c2 - a.c1) * HW) : gb1;
+    asm volatile("" : "+s"(xb1), "+s"(xb2));
+    if constexpr (GATED == 1) asm volatile("" : "+s"(gb1), "+s"(gb2));
     auto fetch = [&](int ci0) {
 #pragma unroll
         for (int k = 0; k < WR; ++k) {
@@ -143,12 +153,11 @@ __global__ void __launch_bounds__(256, WPS) conv3x3_mfma_kernel(const ConvKArgs 
             const int ci = ci0 + c;
             const int cc = ci < cin ? ci : 0;
             const bool first = cc < a.c1;
-            const size_t o = first ? ((size_t)b * a.c1 + cc) * HW : ((size_t)b * a.c2 + (cc - a.c1)) * HW;
-            const float* src = (first ? a.x1 : a.x2) + o;
+            const gfp src = (first ? xb1 : xb2) + (size_t)cc * HW;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) px[c][j] = src[goff[j]];
             if constexpr (GATED == 1) {
-                const float* gsrc = (first ? a.gate1 : a.gate2) + o;
+                const gfp gsrc = (first ? gb1 : gb2) + (size_t)cc * HW;
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) pg[c][j] = gsrc[goff[j]];
             }

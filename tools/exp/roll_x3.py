@@ -1,3 +1,5 @@
+"""The eval rollout of bench.py (rollout_l1: per-pixel L1 and latent flips against the oracle) in the native and in the fp32x3
+mode; under rocprofv3 it also shows which kernels the 2-sample rollout runs (the 128-pixel forms)."""
 import os, sys, torch
 sys.path.insert(0, '.')
 import bench
