@@ -392,11 +392,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_x3_kernel(const ConvKArgs a) {
             const int p = p0 + wave * NPW + 4 * q4;
 #pragma unroll
             for (int i = 0; i < 4; ++i) bits[i] |= (v[i] > 0.f ? 1u : 0u) << row;
-#ifdef X3_NOSTORE
-            if (co < a.cout && v[0] == 12345.f) {
-#else
             if (co < a.cout) {
-#endif
                 float* dst = (co < a.co1 ? a.y1 + ((size_t)b * a.co1 + co) * HW
                                          : a.y2 + ((size_t)b * co2n + (co - a.co1)) * HW) + p;
                 const bool add = a.acc_y1 && co < a.co1;
