@@ -35,7 +35,9 @@ def _err(a, ref):
                                                   (1, 9, 128, 33, 20, 0), (1, 128, 256, 7, 13, 1), (3, 128, 64, 64, 64, 1),
                                                   # 128 workgroups of 512 pixels: the large-tile form of the 128-channel
                                                   # kernel (the small batches above run its 128-pixel form)
-                                                  (16, 32, 128, 64, 64, 1)])
+                                                  (16, 32, 128, 64, 64, 1),
+                                                  # 32- and 48-pixel rows: the weight gradient's 2- and 3-step unrolled forms
+                                                  (2, 64, 128, 12, 32, 1), (2, 40, 128, 9, 48, 0)])
 def test_split_kernels_match_float64_like_the_native_ones(x3, B, cin, cout, H, W, circ):
     ops = x3
     from scm_gan_amd import _lib as L
