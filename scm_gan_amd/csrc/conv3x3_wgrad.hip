@@ -621,6 +621,18 @@ static int wgrad_impl(const scm_conv3x3_wgrad_desc* d, int precision, void* stre
     const int cin = d->c1 + d->c2;
     WgradPlan p;
     wgrad_plan(d->B, d->H, d->W, cin, d->cout, &p);
+    if (precision == SCM_PREC_BF16X3 && d->cout > 64 && p.m16 == 0 && p.mt == 4) {
+        // the split kernel's tiles are 128 co x 32 ci (twice the groups of the plan above): fewer, longer row splits fill
+        // the chip just as well, with half the partial slabs to write and reduce and half the 3-row prologues.  Never
+        // more splits than the plan above, which sized the workspaces.
+        const int groups = p.co_groups * ((cin + 31) / 32);
+        int spi = (256 + d->B * groups - 1) / (d->B * groups);
+        if (spi < 1) spi = 1;
+        if (spi > p.spi) spi = p.spi;
+        p.rows_per_split = (d->H + spi - 1) / spi;       // (56.3-56.6 vs 56.7 ms per configs[1] iteration)
+        p.spi = (d->H + p.rows_per_split - 1) / p.rows_per_split;
+        p.nsplit = d->B * p.spi;
+    }
     WgradKArgs a;
     a.x1 = d->x1; a.x2 = d->x2; a.c1 = d->c1; a.c2 = d->c2;
     a.dy = d->dy; a.gate = d->gate; a.gate_act = d->gate_act; a.cout = d->cout;
