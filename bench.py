@@ -157,6 +157,40 @@ def rollout_l1(dev):
     return float(np.mean(l1)), flips
 
 
+def fp32x3_leg(a, opts, batches, dev, headline):
+    """The timed iteration once more with the 3x3 convolutions in the split mode: throughput, and for the
+    headline workload the eval rollout against the oracle in that mode."""
+    from scm_gan_amd import main as M, ops
+    ops.set_compute_precision("fp32x3")
+    enc2, dec2, rp2, disc2, tr2 = build_nets(0)
+    tr2.seed_noise(1234)
+    trainer2 = M.Trainer(L, A, R, enc2, dec2, rp2, disc2, tr2, opts)
+    for i in range(3):
+        trainer2.step(*batches[i % 2], theta=0.5, train_iter=i + 1)
+    torch.cuda.synchronize()
+    n2 = 10
+    t2 = time.perf_counter()
+    for i in range(n2):
+        trainer2.step(*batches[i % 2], theta=0.5, train_iter=i + 4)
+    torch.cuda.synchronize()
+    dt2 = time.perf_counter() - t2
+    x3 = {"value": a.batch * (a.horizon - 2) * n2 / dt2, "unit": "frames/s", "ms_per_step": dt2 / n2 * 1e3,
+          "steps": n2, "opt_in": "bench.py --precision fp32x3 / main.py --precision fp32x3",
+          "arithmetic": "fp32 operands split exactly into 3 bf16 values, 6 bf16 MFMA products per term, "
+                        "fp32 accumulate; error vs float64 within 2.5x of the native f32 MFMA kernels'"}
+    del trainer2, enc2, dec2, rp2, disc2, tr2
+    if headline:
+        # the north star's own criterion in this mode: the eval rollout against the oracle (per-pixel L1 <= 1e-4,
+        # binary latents).  SCM_X3_ANY_BATCH sends this 2-sample rollout through the split kernels, which the
+        # product would route to the native small tiles.
+        os.environ["SCM_X3_ANY_BATCH"] = "1"
+        try:
+            x3["rollout_l1_vs_ref"], x3["rollout_latent_flips"] = rollout_l1(dev)
+        finally:
+            del os.environ["SCM_X3_ANY_BATCH"]
+    return x3
+
+
 def decoder_leg(dev, batch):
     """Decoder forward + pixel loss in isolation (north star: achieved HBM GB/s on the decoder): ONE fused launch
     (scm_decoder_fused_fwd; the 64-channel hidden map never leaves the chip) + the per-sample loss reduce.
@@ -412,35 +446,13 @@ def main():
             # bf16 split of both operands, six partial products per product, fp32 accumulation: DESIGN.md section 4e).
             # NOT `value`: reported beside it, with the evidence that it is fp32-grade (tests/test_gpu_x3_mode.py; the
             # whole -m gpu parity suite passes in this mode at unchanged tolerances).
-            ops.set_compute_precision("fp32x3")
-            enc2, dec2, rp2, disc2, tr2 = build_nets(0)
-            tr2.seed_noise(1234)
-            trainer2 = M.Trainer(L, A, R, enc2, dec2, rp2, disc2, tr2, opts)
-            for i in range(3):
-                trainer2.step(*batches[i % 2], theta=0.5, train_iter=i + 1)
-            torch.cuda.synchronize()
-            n2 = 10
-            t2 = time.perf_counter()
-            for i in range(n2):
-                trainer2.step(*batches[i % 2], theta=0.5, train_iter=i + 4)
-            torch.cuda.synchronize()
-            dt2 = time.perf_counter() - t2
-            x3 = {"value": a.batch * (a.horizon - 2) * n2 / dt2, "unit": "frames/s", "ms_per_step": dt2 / n2 * 1e3,
-                  "steps": n2, "opt_in": "bench.py --precision fp32x3 / main.py --precision fp32x3",
-                  "arithmetic": "fp32 operands split exactly into 3 bf16 values, 6 bf16 MFMA products per term, "
-                                "fp32 accumulate; error vs float64 within 2.5x of the native f32 MFMA kernels'"}
-            del trainer2, enc2, dec2, rp2, disc2, tr2
-            if headline:
-                # the north star's own criterion in this mode: the eval rollout against the oracle (per-pixel L1 <= 1e-4,
-                # binary latents).  SCM_X3_ANY_BATCH sends this 2-sample rollout through the split kernels, which the
-                # product would route to the native small tiles.
-                os.environ["SCM_X3_ANY_BATCH"] = "1"
-                try:
-                    x3["rollout_l1_vs_ref"], x3["rollout_latent_flips"] = rollout_l1(dev)
-                finally:
-                    del os.environ["SCM_X3_ANY_BATCH"]
-            ops.set_compute_precision("fp32")
-            out["fp32x3"] = x3
+            try:
+                out["fp32x3"] = fp32x3_leg(a, opts, batches, dev, headline)
+            except Exception as e:      # an optional leg must not cost the headline line; the failure stays visible
+                out["fp32x3"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            finally:
+                ops.set_compute_precision("fp32")
+                os.environ.pop("SCM_X3_ANY_BATCH", None)
         if world == 1 and not a.profile_mode:
             out["decoder"] = decoder_leg(dev, a.batch)
         if world == 1 and headline and not a.profile_mode:
