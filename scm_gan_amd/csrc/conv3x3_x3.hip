@@ -6,19 +6,22 @@
 // terms (a_mid b_lo, a_lo b_mid, a_lo b_lo) are <= 2^-23 of the product: one fp32 rounding.  Against a float64
 // reference the result is as close as the native v_mfma_f32_32x32x2_f32 chain (tests/test_gpu_x3_mode.py measures
 // both); it is NOT a reduced-precision mode.  Six bf16 MFMAs cost 6/16 of one f32 MFMA step, so the MFMA-bound
-// 128 -> 128 convolutions of the transition run ~2.5x faster.  Opt-in (ops.set_compute_precision('fp32x3')).
+// 128 -> 128 convolutions of the transition run 1.6-1.7x faster (348 / 381 us against 595 / 608: the split, the LDS
+// stores, the barriers and the epilogue do not shrink with the MFMAs).  Opt-in (ops.set_compute_precision('fp32x3')).
 //
 // Same implicit GEMM, tensors, epilogue and gate handling as conv3x3_h16.hip (which see); differences:
 //   * three LDS images of the halo tile and of the weight chunk (hi / mid / lo), split while staging;
 //   * 512 pixels x up to 128 output channels per workgroup, one workgroup per CU.  The three images of a 16-channel
 //     halo tile (74 KB) stay in LDS while the weights pass through in two 64-channel halves (55 KB each): the tile is
-//     fetched and split once per 128 output channels, 135 KB of LDS in all.
+//     fetched and split once per 128 output channels, 135 KB of LDS in all.  Launches that would leave CUs idle use
+//     128-pixel workgroups instead (PT = 1);
+//   * the next stage's global loads are dealt out over the taps of the running one, LDS operands are read one step
+//     ahead of the MFMAs that use them (what the phase clock below showed).
 #include "conv_args.h"
 #include <type_traits>
 #include <stdlib.h>
 
 #define XKC 16
-#define X3_CT 2
 #define X3_PT 4
 #define X3_NJ 3
 
