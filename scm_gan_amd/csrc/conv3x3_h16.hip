@@ -18,9 +18,12 @@
 // ds_write_b128 of the thread's own registers: no transpose pass.  Consecutive
 // lanes read/write consecutive 16-byte units: conflict-free.
 //
-// Workgroup = 4 waves x PT=4 pixel tiles = 512 pixels x CT*32 output channels,
-// one workgroup per CU (256 accumulator registers + the prefetch registers of a
-// 16-channel chunk), two LDS stages when they fit.
+// Workgroup = 4 waves x PT pixel tiles x CT*32 output channels.  128 output channels on frames up to 64 wide:
+// PT = 2 (256 pixels), one LDS stage, TWO workgroups per CU -- they drift apart, so one's staging, barriers and
+// epilogue (a third of a workgroup's time: the whole chip writing at once) run under the other's MFMAs.
+// Otherwise PT = 4 (512 pixels), one workgroup per CU (256 accumulator registers + the prefetch registers of a
+// 16-channel chunk), two LDS stages when they fit.  The next chunk's global loads are dealt out over the taps, the
+// LDS operands of tap t+1 are read under tap t's MFMAs.
 #include <type_traits>
 #include <stdlib.h>
 #include "conv_args.h"

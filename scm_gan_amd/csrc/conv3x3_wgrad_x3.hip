@@ -10,7 +10,11 @@
 //   * the x row is stored ONCE (plus a halo unit on each side), not as three pre-shifted images -- three components
 //     of three shifted images would not fit the LDS; the kx = 0 / 2 fragments are built in registers from the unit and
 //     its neighbours with five v_alignbit_b32 per (row, component);
-//   * 128 co x 32 ci per workgroup, 4 waves (one per SIMD, the 9 tap accumulators in AGPRs), dy single-buffered.
+//   * 128 co x 32 ci per workgroup, 4 waves (one per SIMD, the 9 tap accumulators in AGPRs), dy single-buffered;
+//     its own row split (twice the groups of the 128 x 64 plan: half the splits, wgrad_impl) and the ci groups of one
+//     split on one XCD (they read the same dy rows);
+//   * whole-group row segments (VEC): validity as bit masks, the 16-pixel step loop unrolled with the next row's
+//     loads dealt out over its steps, LDS operands read a step ahead.
 #include "wgrad_args.h"
 #include <type_traits>
 
