@@ -83,6 +83,11 @@ class GraphedTrainer(object):
         real_ts, t.ts = t.ts, rec
         noise_base = tr._noise_offset
         ops.dev_scalars.update(coef=self._coef, noise_off=self._noise_off, adam_step=self._adam_step)
+        # Every weight pack and SpectralNorm stamp must be REBUILT INSIDE the capture: a pack cached by an eager
+        # forward since the last optimizer step (an evaluate() on the capture iteration) would otherwise be hit
+        # during capture, no pack kernel would be recorded, and every replay would convolve with capture-time
+        # weights while the in-graph Adam keeps updating the real ones.
+        ops.bump_weights_epoch()
         graph = torch.cuda.CUDAGraph()
         try:
             torch.cuda.synchronize()

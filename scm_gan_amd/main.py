@@ -332,9 +332,13 @@ class Trainer(object):
 
 
 def train(latent_dim, datasource, num_actions, num_rewards,
-          encoder, decoder, reward_predictor, discriminator, transition):
+          encoder, decoder, reward_predictor, discriminator, transition, eval_datasource=None):
     """main.py:106-299.  Under torch.distributed (one process per GPU) --batch-size is the GLOBAL
-    batch: every rank draws batch_size / world trajectories from its own datasource stream."""
+    batch: every rank draws batch_size / world trajectories from its own datasource stream.
+    eval_datasource: what the periodic evaluation draws from (default: `datasource`).  Data-parallel runs pass
+    one that is seeded IDENTICALLY on every rank: the evaluation rollout stops early when every trajectory is
+    done (main.py:805), so ranks that evaluated different data could make a different number of SpectralNorm
+    forwards and their u / v -- then their weights -- would drift apart."""
     train_iters = args.train_iters
     trainer = Trainer(latent_dim, num_actions, num_rewards, encoder, decoder, reward_predictor, discriminator,
                       transition)
@@ -361,8 +365,8 @@ def train(latent_dim, datasource, num_actions, num_rewards,
             # EVERY rank evaluates: SpectralNorm advances u / v on every forward, eval included
             # (spectral_normalization.py:66-68), and the iteration depends on the weights only -- so the
             # replicas stay bit-identical only if all of them make the same calls.  Rank 0 writes.
-            evaluate(datasource, encoder, decoder, transition, discriminator, reward_predictor, latent_dim,
-                     train_iter=train_iter, quiet=rank != 0)
+            evaluate(eval_datasource if eval_datasource is not None else datasource, encoder, decoder, transition,
+                     discriminator, reward_predictor, latent_dim, train_iter=train_iter, quiet=rank != 0)
             if world > 1 and args.check_replicas:
                 dp.assert_replicas_identical(nets, 'after the evaluation at iteration %d' % train_iter)
             if rank == 0:
@@ -596,8 +600,10 @@ def main(argv=None):
         evaluate(datasource, encoder, decoder, transition, discriminator, reward_predictor, latent_dim,
                  use_training_set=True)
     else:
+        # every rank evaluates the SAME trajectories (see train()): a second datasource on the un-offset seed
+        eval_ds = allocate_datasource(args.env, seed=args.seed + dp.SEED_STRIDE // 2) if world > 1 else None
         train(latent_dim, datasource, num_actions, num_rewards, encoder, decoder, reward_predictor, discriminator,
-              transition)
+              transition, eval_datasource=eval_ds)
     if rank == 0:
         print('Finished execution, terminating')
     dp.shutdown()

@@ -73,7 +73,7 @@ def _stream():
 # and input-gradient convolutions with more than 16 output channels on frames up to 64 wide; everything else
 # (weight gradients, thin layers, fused decoder / reward head) runs the native fp32 kernels in this mode too.
 PREC_F32, PREC_F16, PREC_BF16, PREC_BF16X3 = L.PREC_F32, L.PREC_F16, L.PREC_BF16, L.PREC_BF16X3
-_precision = [os.environ.get("SCM_PRECISION", "fp32") or "fp32"]      # (the environment default lets the whole fp32 parity suite run in another mode)
+_precision = ["fp32"]
 
 
 def compute_precision():
@@ -84,6 +84,10 @@ def set_compute_precision(name):
     if name not in ("fp32", "fp16", "fp32x3"):
         raise ValueError("compute precision must be 'fp32', 'fp32x3' or 'fp16', got %r" % (name,))
     _precision[0] = name
+
+
+# the environment default lets the whole fp32 parity suite run in another mode; validated like any other value
+set_compute_precision(os.environ.get("SCM_PRECISION", "") or "fp32")
 
 
 # ------------------------------------------------------------------ packs

@@ -30,7 +30,7 @@ def weights_of(nets):
     return torch.cat([p.detach().flatten() for m in nets for p in m.parameters()])
 
 
-def run(graphed, batches, thetas, B, horizon, size):
+def run(graphed, batches, thetas, B, horizon, size, eval_after=None):
     from scm_gan_amd import main as T
     from scm_gan_amd.graph_step import GraphedTrainer
     nets = build(21)
@@ -45,6 +45,15 @@ def run(graphed, batches, thetas, B, horizon, size):
         loss = stepper.step(up(s), up(r), up(d.astype(np.float32)), T.onehot(a, 5), th, i + 1, a)
         snaps.append(weights_of((enc, dec, rp, tr)).clone())
         losses.append(loss.clone())
+        if eval_after is not None and i == eval_after:
+            # what evaluate() does between two training iterations: a no-grad forward through every network
+            # (it fills the weight-pack caches for the CURRENT weights and advances SpectralNorm's u / v)
+            with torch.no_grad():
+                x = up(s)
+                z = enc(x[:, :3])
+                z = tr(z, T.onehot(a, 5)[:, 2])
+                dec(z)
+                rp(z)
     torch.cuda.synchronize()
     return snaps, losses, trainer, stepper
 
@@ -71,6 +80,23 @@ def test_graphed_iterations_are_bitwise_the_eager_ones():
         t.step(up(s), up(r), up(d.astype(np.float32)), T.onehot(a, 5), 0.9, iters + 1, a)
     assert torch.equal(weights_of([te.encoder, te.decoder, te.reward_predictor, te.transition]),
                        weights_of([tg.encoder, tg.decoder, tg.reward_predictor, tg.transition]))
+
+
+def test_capture_right_after_an_eager_forward_rebuilds_the_packs():
+    """an eager no-grad forward (an evaluate()) between the last warm-up iteration and the capture leaves
+    weight packs of the current weights in the caches; the capture must not reuse them (no pack kernel would be
+    recorded and every replay would run on capture-time weights).  Bitwise equality with the eager loop over 4 replays."""
+    from scm_gan_amd.datasource import SyntheticDatasource
+    B, horizon, size, iters = 4, 5, 16, 6
+    ds = SyntheticDatasource(seed=9, height=size, width=size, done_every=3)
+    batches = [ds.get_trajectories(B, horizon) for _ in range(iters)]
+    thetas = [0.5] * iters
+    eager, el, _, _ = run(False, batches, thetas, B, horizon, size, eval_after=1)
+    graph, gl, _, stepper = run(True, batches, thetas, B, horizon, size, eval_after=1)
+    assert stepper.replays == iters - 2
+    for i in range(iters):
+        assert torch.equal(eager[i], graph[i]), (i, float((eager[i] - graph[i]).abs().max()))
+        assert torch.equal(el[i], gl[i]), i
 
 
 def test_graph_replay_at_configs0_size():

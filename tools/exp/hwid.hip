@@ -1,4 +1,5 @@
 // prints how workgroups of a (512 x 256 threads, ~200 VGPR) launch land on CUs / wave slots
+// build: hipcc --offload-arch=gfx950 -O3 tools/exp/hwid.hip -o tools/exp/hwid   (the binary is not kept in git)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <map>

@@ -1,6 +1,7 @@
 // Does a wave that issues f32 MFMAs back to back leave issue slots for another wave's VALU / LDS work on the
 // same SIMD?  One workgroup of 8 waves (2 per SIMD): waves 0-3 run an MFMA loop with CH independent accumulator
 // chains, waves 4-7 run a VALU (or LDS) loop; clock64() around each.
+// build: hipcc --offload-arch=gfx950 -O3 tools/exp/mfma_overlap.hip -o tools/exp/mfma_overlap   (the binary is not kept in git)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
