@@ -264,10 +264,12 @@ def measured_traffic(kernel_name):
     the kernel it was measured on: each file records the sha of the kernel's source file, and a
     file whose sha no longer matches the tree is skipped -> traffic null rather than stale."""
     import glob
-    kind = "h16" if "h16" in kernel_name else ("x3" if "x3_kernel" in kernel_name else "mfma")
-    src = {"h16": "conv3x3_h16.hip", "x3": "conv3x3_x3.hip", "mfma": "conv3x3_mfma.hip"}[kind]
+    kind = "h16" if "h16" in kernel_name else ("x3" if "x3_kernel" in kernel_name else
+                                               ("wino" if "wino" in kernel_name else "mfma"))
+    src = {"h16": "conv3x3_h16.hip", "x3": "conv3x3_x3.hip", "mfma": "conv3x3_mfma.hip", "wino": "conv3x3_wino.hip"}[kind]
     sha = _sha16(os.path.join(ROOT, "scm_gan_amd", "csrc", src))
-    want = {"h16": "conv3x3_h16_kernel<1,", "x3": "conv3x3_x3_kernel<2, 2, 0,", "mfma": "conv3x3_mfma_kernel<4, 2, 2, 0,"}[kind]
+    want = {"h16": "conv3x3_h16_kernel<1,", "x3": "conv3x3_x3_kernel<2, 2, 0,", "mfma": "conv3x3_mfma_kernel<4, 2, 2, 0,",
+            "wino": "conv3x3_wino_kernel<1, 0, 1>"}[kind]
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_pmc*.json")), reverse=True):
         try:
             pmc = json.load(open(f))
@@ -319,6 +321,9 @@ def main():
                     help="MFMA operand precision of the 3x3 convs. fp32 (default) is the reference's arithmetic and the "
                          "only valid headline; fp16 = opt-in fp16 forward / bf16 gradient operands with fp32 accumulation "
                          "(BASELINE configs[4]), reported as a separate, non-headline line")
+    ap.add_argument("--conv-algo", choices=("winograd", "direct"), default=None,
+                    help="fp32 algorithm of the wide 3x3 convolutions (default: the library's, winograd = F(2x2,3x3) on the "
+                         "f32 MFMA pipe; direct = implicit GEMM): both are fp32 operands / fp32 accumulation")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--profile-mode", action="store_true",
@@ -350,6 +355,8 @@ def main():
     from scm_gan_amd import main as M, ops
     from scm_gan_amd.datasource import SyntheticDatasource
     ops.set_compute_precision(a.precision)
+    if a.conv_algo:
+        ops.set_conv_algo(a.conv_algo)
     opts = M.parser.parse_args(["--train-iters", str(a.steps + a.warmup), "--horizon-min", str(a.horizon),
                                 "--horizon-max", str(a.horizon), "--batch-size", str(a.batch * world)]
                                + (["--gan"] if a.config == 2 else []))
@@ -433,12 +440,21 @@ def main():
             # (the split kernels spend six bf16 MFMA products per fp32 product: their roof in fp32 FLOP is the bf16 peak / 6)
             peak = PEAK_F16_MFMA_TFLOPS if "h16" in name else (PEAK_F16_MFMA_TFLOPS / 6.0 if "x3_kernel" in name
                                                              else PEAK_F32_MFMA_TFLOPS)
+            wino = "wino" in name
             out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": peak,
                                "unit": "TFLOP/s", "frac": achieved / peak,
                                "traffic": tr_info["bytes"] if tr_info else None, "traffic_source": tr_info,
                                "launches": s["launches"], "avg_launch_us": s["ms"] * 1e3 / s["launches"],
                                # brackets are recorded on every 5th timed step: scale to the whole timed region
                                "share_of_step": s["ms"] / (dt * 1e3) * a.steps / len(range(0, a.steps, 5))}
+            if wino:
+                # `achieved` counts the ALGORITHMIC FLOPs of the convolution (2 * 9 MACs per output and input channel);
+                # Winograd F(2x2,3x3) issues 4/9 of them on the f32 MFMA pipe, so `frac` can exceed 1 -- the share of
+                # the pipe's peak the kernel really keeps busy is mfma_executed_frac
+                out["roofline"]["algorithm"] = ("Winograd F(2x2,3x3), fp32 operands / fp32 accumulate: 16 MFMA products per "
+                                                "2x2 output patch and channel pair instead of 36")
+                out["roofline"]["mfma_executed_tflops"] = achieved * 4.0 / 9.0
+                out["roofline"]["mfma_executed_frac"] = achieved * 4.0 / 9.0 / peak
             out["kernels"] = {k: {"launches": v["launches"], "ms_total": round(v["ms"], 3),
                                   "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12} for k, v in summ.items()}
         if world == 1 and not a.profile_mode and a.precision == "fp32" and a.size <= 64:

@@ -338,6 +338,23 @@ int scm_pack_conv3x3_weights_x3(const float* w, int cin, int cout, int transpose
 int scm_conv3x3_x3(const scm_conv3x3_desc* d, void* stream);
 
 /* ------------------------------------------------------------------------
+ * The same convolution (same descriptor, same epilogue contract as scm_conv3x3) evaluated by Winograd
+ * F(2x2, 3x3) on the f32 MFMA pipe: Y = A^T [ (G g G^T) .* (B^T d B) ] A, 16 products per 2x2 output patch
+ * and (ci, co) pair instead of 36, fp32 operands and fp32 accumulation throughout (transform entries 0, +-1,
+ * +-1/2).  Replaces the same reference lines as scm_conv3x3 for the wide layers: models.py:78-95 (Transition
+ * conv2..conv5), :147-152 (Encoder conv2 / conv3) and their autograd input gradients.
+ *   wpack : from scm_pack_conv3x3_weights_wino -- the filters already transformed (U = G g G^T), laid out
+ *           [cout group of 64][K chunk of 8 ci][16 positions][2][64][4] (scm_conv3x3_pack_wino_floats floats);
+ *   scm_conv3x3_wino_serves(H, W): 1 when the kernel takes this frame size (any H, W >= 2 whose 64-tile halo
+ *           rows fit its LDS staging map: up to 128 x 128), else 0 -- callers then use scm_conv3x3.
+ * ---------------------------------------------------------------------- */
+size_t scm_conv3x3_pack_wino_floats(int cin, int cout);
+int scm_pack_conv3x3_weights_wino(const float* w, int cin, int cout, int transposed_src, int w_cin_total, int w_ci0,
+                                  float* fwd_pack, float* dgrad_pack, void* stream);
+int scm_conv3x3_wino_serves(int H, int W);
+int scm_conv3x3_wino(const scm_conv3x3_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------
  * Fused decoder + pixel loss: one pass over the latent (SURVEY.md 8(b) scm_decoder_fused_*).
  *
  * Replaces Decoder.forward (models.py:270-291: ConvTranspose2d 16->64 + leaky_relu, ConvTranspose2d

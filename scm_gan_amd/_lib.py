@@ -148,6 +148,10 @@ def lib():
             "scm_conv3x3_pack_x3_bytes": [ci, ci],
             "scm_pack_conv3x3_weights_x3": [vp, ci, ci, ci, ci, ci, vp, vp, vp],
             "scm_conv3x3_x3": [vp, vp],
+            "scm_conv3x3_pack_wino_floats": [ci, ci],
+            "scm_pack_conv3x3_weights_wino": [vp, ci, ci, ci, ci, ci, vp, vp, vp],
+            "scm_conv3x3_wino": [vp, vp],
+            "scm_conv3x3_wino_serves": [ci, ci],
             "scm_decoder_fused_pack_floats": [],
             "scm_decoder_fused_pack": [vp, vp, vp, vp, ci, ci, vp, vp],
             "scm_decoder_fused_workspace": [ci, ci, ci, ci, vp, vp],
@@ -164,6 +168,7 @@ def lib():
             fn.argtypes = args
             fn.restype = ctypes.c_size_t if name in ("scm_conv3x3_pack_floats", "scm_conv2d_bwd_workspace",
                                                   "scm_conv3x3_pack_h16_bytes", "scm_conv3x3_pack_x3_bytes", "scm_decoder_fused_pack_floats",
+                                                  "scm_conv3x3_pack_wino_floats",
                                                   "scm_reward_fused_pack_floats") \
                 else ctypes.c_int
         L._scm_symbols = sorted(sigs) + ["scm_version", "scm_last_error"]

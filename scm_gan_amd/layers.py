@@ -48,7 +48,7 @@ class Conv2d(nn.Module):
         return self.kernel_size == 3 and self.stride == 1 and self.padding == 1
 
     def _get_packs(self, w, cin_conv):
-        key = (w.data_ptr(), w._version, ops.weights_epoch(), cin_conv, w.device, ops.compute_precision())
+        key = (w.data_ptr(), w._version, ops.weights_epoch(), cin_conv, w.device, ops.pack_mode())
         if self._pack_key != key:
             self._packs = ops.pack_conv3x3(w, cin_conv, self.out_channels, False, self.in_channels, 0)
             self._pack_key = key
@@ -116,7 +116,7 @@ class ConvTranspose3x3(nn.Module):
 
     def forward(self, x, act=ops.ACT_NONE):
         w = self.weight
-        key = (w.data_ptr(), w._version, ops.weights_epoch(), w.device, ops.compute_precision())
+        key = (w.data_ptr(), w._version, ops.weights_epoch(), w.device, ops.pack_mode())
         if self._pack_key != key:
             self._packs = ops.pack_conv3x3(w, self.in_channels, self.out_channels, True, self.in_channels, 0)
             self._pack_key = key
@@ -131,7 +131,7 @@ def _convT_factor_sum(self, x, L, C):
     cin = w.shape[0]
     ws = ops.FactorSumFn.apply(w.reshape(cin, L * C, 3, 3), L, C)                    # (cin, C, 3, 3)
     bs = ops.FactorSumFn.apply(self.bias.reshape(1, L * C, 1, 1), L, C).reshape(C)   # (C,)
-    key = (w.data_ptr(), w._version, ops.weights_epoch(), w.device, L, C, ops.compute_precision())
+    key = (w.data_ptr(), w._version, ops.weights_epoch(), w.device, L, C, ops.pack_mode())
     if getattr(self, "_fs_key", None) != key:           # packs depend on the weight values only
         self._fs_packs = ops.pack_conv3x3(ws, cin, C, True, cin, 0)
         self._fs_key = key

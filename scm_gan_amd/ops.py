@@ -73,6 +73,9 @@ def _stream():
 # and input-gradient convolutions with more than 16 output channels on frames up to 64 wide; everything else
 # (weight gradients, thin layers, fused decoder / reward head) runs the native fp32 kernels in this mode too.
 PREC_F32, PREC_F16, PREC_BF16, PREC_BF16X3 = L.PREC_F32, L.PREC_F16, L.PREC_BF16, L.PREC_BF16X3
+# not a precision: the fp32 convolution evaluated by Winograd F(2x2, 3x3) on the f32 MFMA pipe (scm_conv3x3_wino);
+# a pack tagged with it goes to that entry point
+ALGO_WINO = 16
 _precision = ["fp32"]
 
 
@@ -88,6 +91,36 @@ def set_compute_precision(name):
 
 # the environment default lets the whole fp32 parity suite run in another mode; validated like any other value
 set_compute_precision(os.environ.get("SCM_PRECISION", "") or "fp32")
+
+
+# fp32 convolution algorithm of the wide layers: "winograd" (default; F(2x2, 3x3), 4/9 of the direct form's
+# products, fp32 operands and accumulation) or "direct" (implicit GEMM, scm_conv3x3).  Layers thinner than
+# WINO_MIN_CH channels on either side, and frames scm_conv3x3_wino_serves() declines, run the direct kernels.
+_conv_algo = [os.environ.get("SCM_CONV_ALGO", "") or "winograd"]
+WINO_MIN_COUT = int(os.environ.get("SCM_WINO_MIN_COUT", "") or 64)
+WINO_MIN_CIN = int(os.environ.get("SCM_WINO_MIN_CIN", "") or 32)
+
+
+def conv_algo():
+    return _conv_algo[0]
+
+
+def set_conv_algo(name):
+    if name not in ("winograd", "direct"):
+        raise ValueError("convolution algorithm must be 'winograd' or 'direct', got %r" % (name,))
+    _conv_algo[0] = name
+
+
+set_conv_algo(_conv_algo[0])
+
+
+def pack_mode():
+    """What a cached weight pack depends on besides the weights: (operand precision, fp32 algorithm)."""
+    return (_precision[0], _conv_algo[0])
+
+
+def wino_serves(H, W):
+    return bool(L.lib().scm_conv3x3_wino_serves(H, W))
 
 
 # ------------------------------------------------------------------ packs
@@ -122,6 +155,18 @@ def pack_conv3x3(weight, cin, cout, transposed=False, cin_total=0, ci0=0):
                                                     _stream()), "scm_pack_conv3x3_weights_x3")
         return (fx if fx is not None else fp, dx if dx is not None else dp, PREC_BF16X3 if fx is not None else PREC_F32,
                 PREC_BF16X3 if dx is not None else PREC_F32, fp, dp)
+    if _conv_algo[0] == "winograd":
+        # transformed-filter packs for the directions wide enough on both sides; the native packs stay as the
+        # per-call fallback for frames the kernel does not take (wino_serves)
+        fwd_w = cout >= WINO_MIN_COUT and cin >= WINO_MIN_CIN
+        dgr_w = cin >= WINO_MIN_COUT and cout >= WINO_MIN_CIN
+        if fwd_w or dgr_w:
+            fx = _new(w, lib.scm_conv3x3_pack_wino_floats(cin, cout)) if fwd_w else None
+            dx = _new(w, lib.scm_conv3x3_pack_wino_floats(cout, cin)) if dgr_w else None
+            L.check(lib.scm_pack_conv3x3_weights_wino(_p(w), cin, cout, int(transposed), cin_total, ci0, _p(fx), _p(dx),
+                                                      _stream()), "scm_pack_conv3x3_weights_wino")
+            return (fx if fwd_w else fp, dx if dgr_w else dp, ALGO_WINO if fwd_w else PREC_F32,
+                    ALGO_WINO if dgr_w else PREC_F32, fp, dp)
     return fp, dp, PREC_F32, PREC_F32
 
 
@@ -172,6 +217,8 @@ kernel_timer = None     # set to a KernelTimer() to time the MFMA conv launches
 
 
 def conv_kernel_name(cout, prec=0):
+    if prec == ALGO_WINO:
+        return "conv3x3_wino_kernel"
     if prec == PREC_BF16X3:
         return "conv3x3_x3_kernel"
     if prec:
@@ -201,7 +248,9 @@ def _conv3x3_raw(x1, x2, gate1, gate2, gate_act, wpack, cout, scale, bias, sbias
     if kernel_timer is not None:
         ev = kernel_timer.bracket(conv_kernel_name(cout, prec), 2.0 * B * H * W * cout * (c1 + c2) * 9)
         ev[0].record()
-    if prec == PREC_BF16X3:
+    if prec == ALGO_WINO:
+        L.check(lib.scm_conv3x3_wino(ctypes.byref(d), _stream()), "scm_conv3x3_wino")
+    elif prec == PREC_BF16X3:
         L.check(lib.scm_conv3x3_x3(ctypes.byref(d), _stream()), "scm_conv3x3_x3")
     elif prec:
         L.check(lib.scm_conv3x3_h16(ctypes.byref(d), prec, _stream()), "scm_conv3x3_h16")
@@ -310,6 +359,11 @@ class Conv3x3Fn(Function):
             fpack, fprec = cfg["packs"][4], PREC_F32
         if dprec == PREC_BF16X3 and not x3_serves(H, W, B, c1 + c2):
             dpack, dprec = cfg["packs"][5], PREC_F32
+        if ALGO_WINO in (fprec, dprec) and not wino_serves(H, W):
+            if fprec == ALGO_WINO:
+                fpack, fprec = cfg["packs"][4], PREC_F32
+            if dprec == ALGO_WINO:
+                dpack, dprec = cfg["packs"][5], PREC_F32
         sbias = None
         if act_vec is not None:
             A = act_vec.shape[1]
@@ -378,7 +432,7 @@ class Conv3x3Fn(Function):
             d = L.WgradDesc(_p(x1), _p(x2), c1, c2, _p(gy), _p(y) if act else None, act, cout, _p(dw_eff), _p(db),
                             _p(csum), _p(part), _p(cws), B, H, W, cfg["pad"], int(cfg["transposed"]), acc_flag,
                             cin_total, 0, _p(w) if dot_part is not None else None, _p(dot_part), _p(ctx.mask))
-            wprec = ctx.dprec
+            wprec = ctx.dprec if ctx.dprec in (PREC_F16, PREC_BF16) else PREC_F32
             if compute_precision() == "fp32x3":
                 # the split kernel takes 128-wide weight gradients of layers with more than 16 input channels (at any batch:
                 # its work split fills the chip also where the forward's 512-pixel tiles do not)

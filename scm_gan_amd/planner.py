@@ -33,7 +33,7 @@ class GraphedRollout(object):
     def _weights_stamp(self):
         """The graph holds the weight packs that were current at capture: recapture after any update."""
         ps = list(self.transition.parameters()) + list(self.reward_predictor.parameters())
-        return (ops.weights_epoch(), ops.compute_precision(), tuple(p._version for p in ps), tuple(p.data_ptr() for p in ps))
+        return (ops.weights_epoch(), ops.pack_mode(), tuple(p._version for p in ps), tuple(p.data_ptr() for p in ps))
 
     def _rollout(self, z):
         z = z.repeat(self.width, 1, 1, 1)
