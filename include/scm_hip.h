@@ -353,6 +353,10 @@ int scm_pack_conv3x3_weights_wino(const float* w, int cin, int cout, int transpo
                                   float* fwd_pack, float* dgrad_pack, void* stream);
 int scm_conv3x3_wino_serves(int H, int W);
 int scm_conv3x3_wino(const scm_conv3x3_desc* d, void* stream);
+/* Weight / bias gradient (scm_conv3x3_wgrad's descriptor, workspaces and reduce) by the same algorithm:
+ * dL/dg = G^T [ sum over 2x2 output patches of (A dY A^T) .* (B^T d B) ] G.  Serves layers with >= 48 channels on both
+ * sides, W % 4 == 0 and 16-byte aligned tensors; any other call is forwarded to scm_conv3x3_wgrad. */
+int scm_conv3x3_wgrad_wino(const scm_conv3x3_wgrad_desc* d, void* stream);
 
 /* ------------------------------------------------------------------------
  * Fused decoder + pixel loss: one pass over the latent (SURVEY.md 8(b) scm_decoder_fused_*).

@@ -151,6 +151,7 @@ def lib():
             "scm_conv3x3_pack_wino_floats": [ci, ci],
             "scm_pack_conv3x3_weights_wino": [vp, ci, ci, ci, ci, ci, vp, vp, vp],
             "scm_conv3x3_wino": [vp, vp],
+            "scm_conv3x3_wgrad_wino": [vp, vp],
             "scm_conv3x3_wino_serves": [ci, ci],
             "scm_decoder_fused_pack_floats": [],
             "scm_decoder_fused_pack": [vp, vp, vp, vp, ci, ci, vp, vp],

@@ -643,7 +643,12 @@ static int wgrad_impl(const scm_conv3x3_wgrad_desc* d, int precision, void* stre
     a.gate_mask = d->gate_mask;
     hipStream_t s = (hipStream_t)stream;
     int rc;
-    if (precision == SCM_PREC_BF16X3 && d->cout > 64 && p.m16 == 0 && p.mt == 4) {
+    if (precision == SCM_ALGO_WINO && d->cout >= 48 && cin >= 48 && scm_wgrad_wino_serves(a)) {
+        // Winograd F(2x2,3x3) on the f32 MFMA pipe (conv3x3_wgrad_wino.hip); same slabs, its own (coarser) split
+        rc = scm_launch_wgrad_wino(a, p.nsplit, &p.nsplit, &p.spi, s);
+    } else if (precision == SCM_ALGO_WINO) {
+        return wgrad_impl(d, SCM_PREC_F32, stream);          // shapes it does not take: the direct kernels
+    } else if (precision == SCM_PREC_BF16X3 && d->cout > 64 && p.m16 == 0 && p.mt == 4) {
         // fp32 arithmetic on the bf16 MFMA pipe (conv3x3_wgrad_x3.hip); same split, same slabs
         rc = scm_launch_wgrad_x3(a, p, s);
     } else if (precision != SCM_PREC_F32 && precision != SCM_PREC_BF16X3 && d->cout > 64 && p.m16 == 0 && p.mt == 4) {
@@ -690,6 +695,12 @@ static int wgrad_impl(const scm_conv3x3_wgrad_desc* d, int precision, void* stre
 
 extern "C" int scm_conv3x3_wgrad(const scm_conv3x3_wgrad_desc* d, void* stream) {
     return wgrad_impl(d, SCM_PREC_F32, stream);
+}
+
+// The same gradient by Winograd F(2x2,3x3) for layers with at least 48 channels on both sides and 4-pixel-aligned rows
+// (others fall through to the direct kernels): fp32 operands and accumulation, 4/9 of the products.
+extern "C" int scm_conv3x3_wgrad_wino(const scm_conv3x3_wgrad_desc* d, void* stream) {
+    return wgrad_impl(d, SCM_ALGO_WINO, stream);
 }
 
 // Opt-in: the 128 co x 64 ci workgroup tiles run on bf16/fp16 operands (fp32 accumulate, fp32

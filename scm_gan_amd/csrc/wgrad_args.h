@@ -22,3 +22,9 @@ int scm_launch_wgrad_h16(const WgradKArgs& a, const WgradPlan& p, int precision,
 
 // fp32 arithmetic on the bf16 MFMA pipe, 128 co x 32 ci tiles (conv3x3_wgrad_x3.hip)
 int scm_launch_wgrad_x3(const WgradKArgs& a, const WgradPlan& p, hipStream_t s);
+
+// Winograd F(2x2,3x3) weight gradient, 64 co x 64 ci tiles on the f32 MFMA pipe (conv3x3_wgrad_wino.hip): not a
+// precision -- an algorithm tag that travels in wgrad_impl's `precision` argument.  Same slabs, its own split.
+#define SCM_ALGO_WINO 16
+bool scm_wgrad_wino_serves(const WgradKArgs& a);
+int scm_launch_wgrad_wino(const WgradKArgs& a, int max_splits, int* nsplit_out, int* spi_out, hipStream_t s);

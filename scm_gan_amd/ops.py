@@ -439,6 +439,9 @@ class Conv3x3Fn(Function):
                 wprec = PREC_BF16X3 if (W >= 8 and x3_serves(H, W) and cout > 64 and c1 + c2 > 16) else PREC_F32
             if wprec:
                 L.check(lib.scm_conv3x3_wgrad_h16(ctypes.byref(d), wprec, _stream()), "scm_conv3x3_wgrad_h16")
+            elif _conv_algo[0] == "winograd" and compute_precision() == "fp32":
+                # (takes the wide layers, forwards the rest to the direct kernels itself)
+                L.check(lib.scm_conv3x3_wgrad_wino(ctypes.byref(d), _stream()), "scm_conv3x3_wgrad_wino")
             else:
                 L.check(lib.scm_conv3x3_wgrad(ctypes.byref(d), _stream()), "scm_conv3x3_wgrad")
             if has_act:

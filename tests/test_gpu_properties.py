@@ -197,7 +197,7 @@ def test_gate_mask_is_the_sign_of_y_and_gives_identical_gradients(B, cin, cout, 
         x = torch.randn(B, cin, H, W, device="cuda")
         w = torch.randn(cout, cin, 3, 3, device="cuda") * 0.05
         bias = torch.randn(cout, device="cuda") * 0.1
-        fp, dp, fprec, dprec = ops.pack_conv3x3(w, cin, cout)
+        fp, dp, fprec, dprec = ops.pack_conv3x3(w, cin, cout)[:4]      # (the default fp32 algorithm: Winograd where it serves)
         nw = (cout + 31) // 32
         mask = torch.zeros(B, nw, H, W, device="cuda", dtype=torch.int32)
         y, _ = ops._conv3x3_raw(x, None, None, None, 0, fp, cout, None, bias, None, cout, circ, ops.ACT_LRELU, fprec,
@@ -222,7 +222,7 @@ def test_gate_mask_is_the_sign_of_y_and_gives_identical_gradients(B, cin, cout, 
             db = torch.empty(cout, device="cuda")
             d = L.WgradDesc(P(x), None, cin, 0, P(gy), P(y), ops.ACT_LRELU, cout, P(dw), P(db), None, P(part), P(cws), B, H, W,
                             circ, 0, 0, 0, 0, None, None, P(mk))
-            if dprec:
+            if dprec in (ops.PREC_F16, ops.PREC_BF16):
                 L.check(lib.scm_conv3x3_wgrad_h16(ctypes.byref(d), dprec, S()), "wgrad_h16")
             else:
                 L.check(lib.scm_conv3x3_wgrad(ctypes.byref(d), S()), "wgrad")

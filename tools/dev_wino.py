@@ -150,7 +150,95 @@ def timing():
             res[0], fl / res[0] / 1e6, res[1], fl / res[1] / 1e6, res[1] / res[0]))
 
 
-if __name__ == '__main__':
+if __name__ == '__main__' and 'wgrad' not in sys.argv:
     ok = check()
     if ok or 'time' in sys.argv:
         timing()
+
+
+# ---------------------------------------------------------------- weight gradient
+def wgrad(wino, x1, x2, dy, gate, gate_act, pad, mask=None, want_csum=True):
+    B, c1, H, W = x1.shape; c2 = 0 if x2 is None else x2.shape[1]; cout = dy.shape[1]; cin = c1 + c2
+    pf = ctypes.c_size_t(); cf = ctypes.c_size_t()
+    L.check(lib.scm_conv3x3_wgrad_workspace(B, H, W, cin, cout, ctypes.byref(pf), ctypes.byref(cf)), 'ws')
+    part = torch.empty(pf.value, device=dev); cs = torch.empty(cf.value, device=dev)
+    dw = torch.empty((cout, cin, 3, 3), device=dev)
+    db = torch.empty(cout, device=dev); csum = torch.empty(B, cout, device=dev)
+    d = L.WgradDesc(L.ptr(x1), L.ptr(x2), c1, c2, L.ptr(dy), L.ptr(gate), gate_act, cout, L.ptr(dw), L.ptr(db),
+                    L.ptr(csum) if want_csum else None, L.ptr(part), L.ptr(cs), B, H, W, pad, 0, 0, 0, 0, None, None,
+                    None if mask is None else ctypes.c_void_p(mask.data_ptr()))
+    fn = lib.scm_conv3x3_wgrad_wino if wino else lib.scm_conv3x3_wgrad
+    L.check(fn(ctypes.byref(d), L.stream_ptr()), 'wgrad')
+    return dw, db, csum
+
+
+def mask_of(y):
+    B, cout, H, W = y.shape
+    nw = (cout + 31) // 32
+    bits = (y > 0).to(torch.int64)
+    padc = nw * 32 - cout
+    if padc: bits = torch.cat([bits, torch.zeros(B, padc, H, W, device=y.device, dtype=torch.int64)], 1)
+    words = (bits.view(B, nw, 32, H, W) << torch.arange(32, device=y.device).view(1, 1, 32, 1, 1)).sum(2)
+    return torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32).contiguous()
+
+
+def check_wgrad():
+    torch.manual_seed(1)
+    ok = True
+    for (B, c1, c2, cout, H, W, pad, act) in [
+            (2, 64, 0, 64, 16, 16, 1, 1), (2, 128, 128, 128, 16, 16, 1, 1), (2, 128, 0, 128, 16, 16, 0, 1),
+            (1, 64, 0, 64, 20, 12, 0, 1), (3, 64, 0, 48, 20, 12, 0, 0), (1, 128, 0, 128, 64, 64, 1, 1),
+            (1, 100, 0, 128, 84, 84, 1, 1), (1, 128, 0, 128, 128, 128, 0, 1), (2, 70, 0, 70, 9, 8, 1, 1),
+            (2, 70, 0, 70, 9, 8, 0, 2), (1, 64, 0, 64, 33, 24, 1, 0), (2, 64, 64, 100, 6, 8, 0, 1),
+            (1, 64, 0, 64, 2, 4, 1, 0), (4, 128, 0, 128, 32, 32, 1, 1), (1, 64, 0, 64, 10, 100, 0, 1)]:
+        x1 = torch.randn(B, c1, H, W); x2 = torch.randn(B, c2, H, W) if c2 else None
+        w = (torch.randn(cout, c1 + c2, 3, 3) * 0.05).double().requires_grad_(True)
+        bb = torch.randn(cout).double().requires_grad_(True)
+        xin = (x1 if x2 is None else torch.cat([x1, x2], 1)).double()
+        y = ref_conv(xin, w, bb, pad, act)
+        dy = torch.randn_like(y)
+        y.backward(dy)
+        yf = y.detach().float().to(dev)
+        res = {}
+        for mode in (['float', 'mask'] if (act == 1 and cout > 32) else ['float']):
+            for wino in (1, 0):
+                dw, db, csum = wgrad(wino, x1.to(dev), None if x2 is None else x2.to(dev), dy.float().to(dev), yf, act, pad,
+                                     mask=mask_of(yf) if mode == 'mask' else None)
+                sc = max(1.0, w.grad.abs().max().item())
+                e1 = (dw.cpu().double() - w.grad).abs().max().item() / sc
+                e2 = (db.cpu().double() - bb.grad).abs().max().item() / max(1.0, bb.grad.abs().max().item())
+                e3 = (csum.sum(0).cpu().double() - bb.grad).abs().max().item() / max(1.0, bb.grad.abs().max().item())
+                res[(mode, wino)] = (e1, e2, e3)
+        line = ' '.join('%s/%s dw %.1e db %.1e cs %.1e' % (m, 'wino' if wn else 'direct', *res[(m, wn)]) for (m, wn) in res)
+        print('wgrad', (B, c1, c2, cout, H, W, pad, act), line)
+        for (m, wn), (e1, e2, e3) in res.items():
+            if wn: ok &= e1 < 1e-5 and e2 < 1e-5 and e3 < 1e-5
+    print('WGRAD ALL OK' if ok else 'WGRAD FAILED')
+    return ok
+
+
+def timing_wgrad():
+    for (B, c1, c2, cout, H, W) in [(64, 128, 0, 128, 64, 64), (64, 128, 128, 128, 64, 64), (8, 128, 0, 128, 64, 64),
+                                    (16, 128, 0, 128, 84, 84), (16, 128, 0, 128, 128, 128)]:
+        x1 = torch.randn(B, c1, H, W, device=dev); x2 = torch.randn(B, c2, H, W, device=dev) if c2 else None
+        dy = torch.randn(B, cout, H, W, device=dev); g = torch.randn(B, cout, H, W, device=dev)
+        m = mask_of(g)
+        res = []
+        for wino in (1, 0):
+            for _ in range(3): wgrad(wino, x1, x2, dy, g, 1, 1, mask=m)
+            torch.cuda.synchronize()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            n = 10
+            s.record()
+            for _ in range(n): wgrad(wino, x1, x2, dy, g, 1, 1, mask=m)
+            e.record(); torch.cuda.synchronize()
+            res.append(s.elapsed_time(e) / n * 1e3)
+        fl = 2.0 * B * H * W * cout * (c1 + c2) * 9
+        print('wgrad time', (B, c1, c2, cout, H, W), 'wino %.1f us (%.1f TF algorithmic)  direct %.1f us (%.1f TF)  x%.2f' % (
+            res[0], fl / res[0] / 1e6, res[1], fl / res[1] / 1e6, res[1] / res[0]))
+
+
+if __name__ == '__main__' and 'wgrad' in sys.argv:
+    ok = check_wgrad()
+    if ok or 'time' in sys.argv:
+        timing_wgrad()
