@@ -359,10 +359,13 @@ class Conv3x3Fn(Function):
             fpack, fprec = cfg["packs"][4], PREC_F32
         if dprec == PREC_BF16X3 and not x3_serves(H, W, B, c1 + c2):
             dpack, dprec = cfg["packs"][5], PREC_F32
-        if ALGO_WINO in (fprec, dprec) and not wino_serves(H, W):
-            if fprec == ALGO_WINO:
+        if ALGO_WINO in (fprec, dprec):
+            # frames / operand layouts the Winograd kernels do not take run the direct kernels (native packs)
+            frame_ok = wino_serves(H, W)
+            if fprec == ALGO_WINO and not (frame_ok and (c2 == 0 or c1 % 8 == 0) and x1.data_ptr() % 8 == 0
+                                           and (x2 is None or x2.data_ptr() % 8 == 0)):
                 fpack, fprec = cfg["packs"][4], PREC_F32
-            if dprec == ALGO_WINO:
+            if dprec == ALGO_WINO and not frame_ok:
                 dpack, dprec = cfg["packs"][5], PREC_F32
         sbias = None
         if act_vec is not None:
@@ -400,8 +403,11 @@ class Conv3x3Fn(Function):
             # input gradient in the shared cell, the other adds into that buffer in its gradient conv's epilogue
             cell1, cell2 = cfg.get("dx1_cell"), cfg.get("dx2_cell")
             acc1 = cell1.get("buf") if cell1 is not None else None
+            dprec = ctx.dprec
+            if dprec == ALGO_WINO and (gy.data_ptr() | y.data_ptr()) % 8:
+                dpack, dprec = cfg["packs"][5], PREC_F32          # (an oddly offset gradient view: direct kernel)
             dx1, dx2 = _conv3x3_raw(gy, None, y if act else None, None, act, dpack, c1 + c2, inv_sigma, None, None, c1,
-                                    cfg["pad"], ACT_NONE, ctx.dprec, mask_in=ctx.mask, y1_acc=acc1)
+                                    cfg["pad"], ACT_NONE, dprec, mask_in=ctx.mask, y1_acc=acc1)
             if cell1 is not None:
                 cell1["buf"] = dx1
             if cell2 is not None and dx2 is not None:

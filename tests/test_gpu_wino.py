@@ -1,0 +1,200 @@
+"""GPU (-m gpu): the Winograd F(2x2, 3x3) form of the wide fp32 convolutions (csrc/conv3x3_wino.hip,
+conv3x3_wgrad_wino.hip; the default algorithm, ops.set_conv_algo) -- forward, gated input gradient and weight / bias
+gradient through the C ABI against FLOAT64, next to the direct implicit-GEMM kernels on the same data.
+
+What is claimed and tested: it is the same fp32 operator (fp32 operands, fp32 MFMA accumulation, transforms with
+entries 0, +-1, +-1/2), so its error against float64 is of the direct kernels' size (measured 0.3x .. 1.5x: it sums
+fewer products), the 1-bit gate it writes is the sign of its own output, the epilogue contract (scale, bias,
+per-sample bias, split outputs, accumulate) is the direct kernel's, results are bitwise reproducible, and frames it
+does not take (odd widths) silently run the direct kernels.  The reference-generated golden tests and the full-size
+property tests run in this algorithm by default; `SCM_CONV_ALGO=direct` re-runs the suite on the direct kernels."""
+import ctypes
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [  # B, c1, c2, cout, H, W, circular, act
+    (2, 32, 0, 64, 16, 16, 1, 1), (2, 128, 128, 128, 16, 16, 1, 1), (2, 9, 0, 128, 16, 16, 0, 1),
+    (1, 16, 0, 64, 20, 12, 0, 1), (3, 64, 0, 48, 20, 12, 0, 0), (1, 128, 0, 128, 64, 64, 1, 1),
+    (1, 21, 0, 128, 84, 84, 1, 1), (1, 8, 0, 256, 16, 16, 1, 0), (1, 128, 0, 128, 128, 128, 0, 1),
+    (2, 40, 0, 70, 9, 8, 1, 1), (2, 40, 0, 70, 9, 8, 0, 2), (1, 24, 0, 64, 33, 22, 1, 0), (2, 16, 8, 100, 6, 6, 0, 1),
+    (1, 12, 0, 64, 2, 2, 1, 0), (1, 12, 0, 64, 3, 6, 0, 0), (2, 128, 0, 128, 32, 32, 1, 1), (1, 64, 0, 64, 10, 100, 0, 1)]
+WSHAPES = [
+    (2, 64, 0, 64, 16, 16, 1, 1), (2, 128, 128, 128, 16, 16, 1, 1), (2, 128, 0, 128, 16, 16, 0, 1),
+    (1, 64, 0, 64, 20, 12, 0, 1), (3, 64, 0, 48, 20, 12, 0, 0), (1, 128, 0, 128, 64, 64, 1, 1),
+    (1, 100, 0, 128, 84, 84, 1, 1), (1, 128, 0, 128, 128, 128, 0, 1), (2, 70, 0, 70, 9, 8, 1, 1),
+    (2, 70, 0, 70, 9, 8, 0, 2), (1, 64, 0, 64, 33, 24, 1, 0), (2, 64, 64, 100, 6, 8, 0, 1),
+    (1, 64, 0, 64, 2, 4, 1, 0), (4, 128, 0, 128, 32, 32, 1, 1), (1, 64, 0, 64, 10, 100, 0, 1)]
+
+
+@pytest.fixture(scope="module")
+def K():
+    from scm_gan_amd import _lib as L
+
+    class Kit(object):
+        lib = L.lib()
+        P = staticmethod(lambda t: None if t is None else ctypes.c_void_p(t.data_ptr()))
+        S = staticmethod(lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+
+        def pack(self, w, wino):
+            cout, cin = w.shape[:2]
+            size = self.lib.scm_conv3x3_pack_wino_floats if wino else self.lib.scm_conv3x3_pack_floats
+            fn = self.lib.scm_pack_conv3x3_weights_wino if wino else self.lib.scm_pack_conv3x3_weights
+            fp, dp = torch.empty(size(cin, cout), device="cuda"), torch.empty(size(cout, cin), device="cuda")
+            L.check(fn(self.P(w), cin, cout, 0, 0, 0, self.P(fp), self.P(dp), self.S()), "pack")
+            return fp, dp
+
+        def conv(self, wino, x1, x2, wp, cout, pad, act, bias=None, sbias=None, scale=None, gate1=None, gate_act=0,
+                 co1=None, mask_out=None, mask_in=None, y1_acc=None):
+            B, c1, H, W = x1.shape
+            c2 = 0 if x2 is None else x2.shape[1]
+            co1 = cout if co1 is None else co1
+            y1 = torch.empty(B, co1, H, W, device="cuda") if y1_acc is None else y1_acc
+            y2 = torch.empty(B, cout - co1, H, W, device="cuda") if co1 < cout else None
+            d = L.ConvDesc(self.P(x1), self.P(x2), c1, c2, self.P(gate1), None, gate_act, self.P(wp), cout, self.P(scale),
+                           self.P(bias), self.P(sbias), self.P(y1), self.P(y2), co1, B, H, W, pad, act, self.P(mask_out),
+                           self.P(mask_in), 0 if y1_acc is None else 1)
+            L.check((self.lib.scm_conv3x3_wino if wino else self.lib.scm_conv3x3)(ctypes.byref(d), self.S()), "conv")
+            return y1, y2
+
+        def wgrad(self, wino, x1, x2, dy, gate, gate_act, pad, mask=None):
+            B, c1, H, W = x1.shape
+            c2 = 0 if x2 is None else x2.shape[1]
+            cout, cin = dy.shape[1], c1 + c2
+            pf, cf = ctypes.c_size_t(), ctypes.c_size_t()
+            L.check(self.lib.scm_conv3x3_wgrad_workspace(B, H, W, cin, cout, ctypes.byref(pf), ctypes.byref(cf)), "ws")
+            part, cs = torch.empty(pf.value, device="cuda"), torch.empty(cf.value, device="cuda")
+            dw, db, csum = torch.empty(cout, cin, 3, 3, device="cuda"), torch.empty(cout, device="cuda"), torch.empty(B, cout, device="cuda")
+            d = L.WgradDesc(self.P(x1), self.P(x2), c1, c2, self.P(dy), self.P(gate), gate_act, cout, self.P(dw), self.P(db),
+                            self.P(csum), self.P(part), self.P(cs), B, H, W, pad, 0, 0, 0, 0, None, None, self.P(mask))
+            L.check((self.lib.scm_conv3x3_wgrad_wino if wino else self.lib.scm_conv3x3_wgrad)(ctypes.byref(d), self.S()), "wgrad")
+            return dw, db, csum
+    return Kit()
+
+
+def ref_conv(x, w, b, pad, act):
+    if pad == 1:
+        y = F.conv2d(F.pad(x, (1, 1, 1, 1), mode="circular"), w, b)
+    else:
+        y = F.conv2d(x, w, b, padding=1)
+    return F.leaky_relu(y) if act == 1 else (torch.sigmoid(y) if act == 2 else y)
+
+
+def mask_words(y):
+    """[B][ceil(C/32)][H][W] int32 words, bit j of word w = (channel 32w + j of y > 0)."""
+    B, C, H, W = y.shape
+    nw = (C + 31) // 32
+    bits = (y > 0).to(torch.int64)
+    if nw * 32 > C:
+        bits = torch.cat([bits, torch.zeros(B, nw * 32 - C, H, W, device=y.device, dtype=torch.int64)], 1)
+    words = (bits.view(B, nw, 32, H, W) << torch.arange(32, device=y.device).view(1, 1, 32, 1, 1)).sum(2)
+    return torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32).contiguous()
+
+
+@pytest.mark.parametrize("B,c1,c2,cout,H,W,pad,act", SHAPES)
+def test_forward_and_input_gradient_vs_float64(K, B, c1, c2, cout, H, W, pad, act):
+    torch.manual_seed(0)
+    x1 = torch.randn(B, c1, H, W)
+    x2 = torch.randn(B, c2, H, W) if c2 else None
+    w = torch.randn(cout, c1 + c2, 3, 3) * 0.05
+    b, sb, sc = torch.randn(cout), torch.randn(B, cout) * 0.3, torch.tensor([0.7])
+    xin = x1 if x2 is None else torch.cat([x1, x2], 1)
+    yr = ref_conv(xin.double(), w.double() * 0.7, b.double(), pad, 0) + sb.double()[:, :, None, None]
+    yr = F.leaky_relu(yr) if act == 1 else (torch.sigmoid(yr) if act == 2 else yr)
+    err, ys = {}, {}
+    for wino in (1, 0):
+        fp, _ = K.pack(w.cuda(), wino)
+        mask = torch.zeros(B, (cout + 31) // 32, H, W, device="cuda", dtype=torch.int32) if (act == 1 and cout > 32) else None
+        y1, y2 = K.conv(wino, x1.cuda(), None if x2 is None else x2.cuda(), fp, cout, pad, act, bias=b.cuda(), sbias=sb.cuda(),
+                        scale=sc.cuda(), co1=128 if cout == 256 else None, mask_out=mask)
+        y = y1 if y2 is None else torch.cat([y1, y2], 1)
+        err[wino], ys[wino] = float((y.cpu().double() - yr).abs().max()), (y, mask)
+    assert err[1] < 1e-5 and err[1] <= 2.0 * err[0] + 1e-7, err
+    y, mask = ys[1]
+    if mask is not None:            # the 1-bit gate is the sign of THIS kernel's output
+        got, want = mask, mask_words(y)
+        if cout % 32:
+            keep = (1 << (cout % 32)) - 1
+            got, want = got.clone(), want.clone()
+            got[:, -1] &= keep
+            want[:, -1] &= keep
+        assert torch.equal(got, want)
+    # input gradient: dx = conv(dy * lrelu'(y), dgrad pack), split into dx1 / dx2 with dx1 accumulated into a buffer;
+    # float gate and 1-bit gate
+    xin_r = xin.double().requires_grad_(True)
+    yr2 = ref_conv(xin_r, w.double(), None, pad, 1)
+    dy = torch.randn_like(yr2)
+    yr2.backward(dy)
+    yf = yr2.detach().float().cuda()
+    for mode in ("float", "mask"):
+        if mode == "mask" and cout <= 32:
+            continue
+        e = {}
+        for wino in (1, 0):
+            _, dp = K.pack(w.cuda(), wino)
+            base = torch.randn(B, c1, H, W, device="cuda") if c2 else None
+            dx1, dx2 = K.conv(wino, dy.float().cuda(), None, dp, c1 + c2, pad, 0, gate1=yf, gate_act=1, co1=c1 if c2 else None,
+                              mask_in=mask_words(yf) if mode == "mask" else None, y1_acc=None if base is None else base.clone())
+            if base is not None:
+                dx1 = dx1 - base
+            dx = dx1 if dx2 is None else torch.cat([dx1, dx2], 1)
+            e[wino] = float((dx.cpu().double() - xin_r.grad).abs().max())
+        assert e[1] < 2e-5 and e[1] <= 2.0 * e[0] + 1e-7, (mode, e)
+
+
+@pytest.mark.parametrize("B,c1,c2,cout,H,W,pad,act", WSHAPES)
+def test_weight_gradient_vs_float64(K, B, c1, c2, cout, H, W, pad, act):
+    torch.manual_seed(1)
+    x1 = torch.randn(B, c1, H, W)
+    x2 = torch.randn(B, c2, H, W) if c2 else None
+    w = (torch.randn(cout, c1 + c2, 3, 3) * 0.05).double().requires_grad_(True)
+    bb = torch.randn(cout).double().requires_grad_(True)
+    xin = (x1 if x2 is None else torch.cat([x1, x2], 1)).double()
+    y = ref_conv(xin, w, bb, pad, act)
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    yf = y.detach().float().cuda()
+    sw, sb = max(1.0, float(w.grad.abs().max())), max(1.0, float(bb.grad.abs().max()))
+    for mode in (("float", "mask") if (act == 1 and cout > 32) else ("float",)):
+        e = {}
+        for wino in (1, 0):
+            dw, db, csum = K.wgrad(wino, x1.cuda(), None if x2 is None else x2.cuda(), dy.float().cuda(), yf, act, pad,
+                                   mask=mask_words(yf) if mode == "mask" else None)
+            e[wino] = (float((dw.cpu().double() - w.grad).abs().max()) / sw, float((db.cpu().double() - bb.grad).abs().max()) / sb,
+                       float((csum.sum(0).cpu().double() - bb.grad).abs().max()) / sb)
+        assert max(e[1]) < 2e-6 and e[1][0] <= 3.0 * e[0][0] + 1e-8, (mode, e)
+
+
+def test_bitwise_reproducible_and_layer_fallback():
+    """Two launches give identical bits (fixed summation order, no atomics); a layer on a frame the kernels do not take
+    (odd width) runs the direct kernels through the same autograd function and agrees with the direct algorithm bitwise."""
+    from scm_gan_amd import ops
+    from scm_gan_amd.layers import Conv2d
+    assert ops.conv_algo() in ("winograd", "direct")
+    prev = ops.conv_algo()
+    try:
+        outs = {}
+        for algo in ("winograd", "winograd", "direct"):
+            ops.set_conv_algo(algo)
+            torch.manual_seed(3)
+            layer = Conv2d(128, 128, 3, padding=2, padding_mode="circular").cuda()
+            res = []
+            for (H, W) in ((16, 16), (9, 7)):
+                x = torch.randn(2, 128, H, W, device="cuda", requires_grad=True)
+                yy = layer(x, act=ops.ACT_LRELU)
+                yy.backward(torch.ones_like(yy) * 1e-3)
+                res += [yy.detach().clone(), x.grad.clone(), layer.weight.grad.clone()]
+                layer.weight.grad = None
+            outs.setdefault(algo, []).append(res)
+        a, b = outs["winograd"]
+        assert all(torch.equal(p, q) for p, q in zip(a, b))
+        d = outs["direct"][0]
+        # 16 x 16: two algorithms, fp32-rounding apart; 9 x 7: both ran the direct kernels
+        assert all(float((p - q).abs().max()) < 1e-4 * max(1.0, float(q.abs().max())) for p, q in zip(a[:3], d[:3]))
+        assert not torch.equal(a[0], d[0])
+        assert all(torch.equal(p, q) for p, q in zip(a[3:], d[3:]))
+    finally:
+        ops.set_conv_algo(prev)
