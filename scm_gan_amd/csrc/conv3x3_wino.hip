@@ -33,6 +33,10 @@
 #define WINO_TILES 64     // tiles per workgroup
 #define WINO_CO 64        // output channels per workgroup
 #define WINO_SLAB 8192    // floats of one (co group, K chunk) weight slab: [16][2][64][4]
+#ifndef WINO_UR
+#define WINO_UR 8         // A-operand ring: slots and prefetch distance in positions (measured: 8 / 6, 12 / 10 and
+#define WINO_UD 6         // 16 / 14 run the K loop in 5 171 / 5 231 / 5 237 ticks per chunk: latency is covered at 6)
+#endif
 
 typedef unsigned u32x2w __attribute__((ext_vector_type(2)));
 
@@ -66,7 +70,8 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_kernel(const ConvKArgs a)
     const int W = a.W, H = a.H, HW = H * W;           // W is even (scm_conv3x3_wino_serves)
     const int TCW = W >> 1, TRH = (H + 1) >> 1;
     const int ntiles = TCW * TRH;
-    const int ROWPL = W + 4;                          // raw row: columns ix = -2 .. W+1 (aligned pairs)
+    const int ROWPL = W + 6;                          // raw row: image column ix sits at ix + 3 (ix = -2 .. W+1; slot 0 unused):
+                                                      // global pairs stay 8-byte aligned, patch reads (from ix = 2*tx-1) too
 
     const int b = blockIdx.x / a.tiles_per_img;
     const int wt = blockIdx.x - b * a.tiles_per_img;
@@ -76,7 +81,8 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_kernel(const ConvKArgs a)
     int tlast = t0 + WINO_TILES - 1;
     if (tlast > ntiles - 1) tlast = ntiles - 1;
     const int nrows = 2 * (tlast / TCW - ty0) + 4;
-    const int npair = (nrows * ROWPL) >> 1;
+    const int HPR = (W + 4) >> 1;                     // pairs per raw row
+    const int npair = nrows * HPR;
 
     if (tid < WINO_CO) {      // bias table for the epilogue (visible after the main loop's barriers)
         const int co = cg * WINO_CO + tid;
@@ -94,15 +100,15 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_kernel(const ConvKArgs a)
     // padding they are masked.  poff[j]: byte offset of the source pair in a channel plane (always a real pair);
     // bit j of okmask: written as loaded; otherwise written as 0.
     unsigned poff[NJ];
+    int rawi[NJ];            // where the pair lands in a raw plane (odd index: two 4-byte stores in one instruction)
     unsigned okmask = 0u;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int q = tid + 256 * j;
         int g = 0;
         if (q < npair) {
-            const int hp = ROWPL >> 1;
-            const int r = q / hp;
-            int iy = 2 * ty0 - 1 + r, ix = 2 * (q - r * hp) - 2;
+            const int r = q / HPR;
+            int iy = 2 * ty0 - 1 + r, ix = 2 * (q - r * HPR) - 2;
             bool ok = true;
             if (PADC) {
                 iy = iy < 0 ? iy + H : (iy >= H ? iy - H : iy);
@@ -116,15 +122,16 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_kernel(const ConvKArgs a)
             if (ok) okmask |= 1u << j;
         }
         poff[j] = (unsigned)g * 4u;
+        { const int r = q / HPR; rawi[j] = q < npair ? r * ROWPL + 2 * (q - r * HPR) + 1 : 0; }   // (slots 0, 1 are never read)
     }
 
     // this thread's transform item: tile (lane) x channel pair (wave) of the chunk
-    int traw;               // offset of its 4x4 patch (raw column 2*tx + 1 = image column 2*tx - 1) in a raw plane
+    int traw;               // offset of its 4x4 patch (raw slot 2*tx + 2 = image column 2*tx - 1, even) in a raw plane
     {
         int t = t0 + lane;
         if (t > ntiles - 1) t = ntiles - 1;
         const int ty = t / TCW, tx = t - ty * TCW;
-        traw = 2 * (ty - ty0) * ROWPL + 2 * tx + 1;
+        traw = 2 * (ty - ty0) * ROWPL + 2 * tx + 2;
     }
 
     f32x16 acc[16];
@@ -157,8 +164,8 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_kernel(const ConvKArgs a)
     for (int k = 0; k < 4; ++k) uoff[k] = lane * 16 + k * 4096;
 
     // ---- registers that live across the K loop
-    float ur[8][4];         // ring of A operands (transformed filters), straight from global / L2: position F of a chunk
-                            // sits in ur[F & 7], requested 6 positions ahead
+    float ur[WINO_UR][4];   // ring of A operands (transformed filters), straight from global / L2: position F of a chunk
+                            // sits in ur[F % WINO_UR], requested WINO_UD positions ahead (L2 latency under load: ~1 us)
     float bq[2][4];         // B operands (V) of the current and the next position
     float px[KC][NJ][2];    // raw halo pairs of the NEXT chunk (requested a whole iteration ahead)
     float pg[GATED == 1 ? KC : 1][GATED == 1 ? NJ : 1][2];
@@ -176,7 +183,8 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_kernel(const ConvKArgs a)
         gcp base = ub + (unsigned)clampc(chunk) * (unsigned)(WINO_SLAB * 4);
         asm volatile("" : "+s"(base));
         const f32x4 t = *(gfp4)(base + vo(uoff[F >> 2]) + (F & 3) * 1024);
-        ur[F & 7][0] = t[0]; ur[F & 7][1] = t[1]; ur[F & 7][2] = t[2]; ur[F & 7][3] = t[3];
+        constexpr int R = F % WINO_UR;
+        ur[R][0] = t[0]; ur[R][1] = t[1]; ur[R][2] = t[2]; ur[R][3] = t[3];
     };
     // Raw halo pairs of local channel C of `chunk` -> px[C] (+ gate tensor pairs).  The channel pointer runs: set at
     // C = 0 (one 64-bit multiply per chunk), advanced by one plane per channel while the next one exists -- a channel
@@ -240,7 +248,8 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_kernel(const ConvKArgs a)
                 v[0] = ok ? v[0] : 0.f;
                 v[1] = ok ? v[1] : 0.f;
             }
-            *reinterpret_cast<f32x2*>(RAW + C * PLANE + 2 * (tid + 256 * j)) = v;
+            float* rp = RAW + C * PLANE + rawi[j];
+            rp[0] = v[0]; rp[1] = v[1];
         }
     };
     // Input transform B^T d B of this thread's patches (tile = lane, local channels 2*wave and 2*wave+1), in pieces
@@ -249,9 +258,9 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_kernel(const ConvKArgs a)
     // (MFMA k index of local channel c: half = c >> 2, step = c & 3)
     auto t_rd = [&](auto cc_, auto i_) {
         constexpr int CC = decltype(cc_)::value, I = decltype(i_)::value;
-        const float* rp = RAW + (2 * wave + CC) * PLANE + traw + I * ROWPL;     // odd offset: b32 | aligned b64 | b32
-        const f32x2 mid = *reinterpret_cast<const f32x2*>(rp + 1);
-        dd[CC][I][0] = rp[0]; dd[CC][I][1] = mid[0]; dd[CC][I][2] = mid[1]; dd[CC][I][3] = rp[3];
+        const float* rp = RAW + (2 * wave + CC) * PLANE + traw + I * ROWPL;
+        const f32x2 lo = *reinterpret_cast<const f32x2*>(rp), hi = *reinterpret_cast<const f32x2*>(rp + 2);
+        dd[CC][I][0] = lo[0]; dd[CC][I][1] = lo[1]; dd[CC][I][2] = hi[0]; dd[CC][I][3] = hi[1];
     };
     auto t_col = [&](auto cc_, auto i_) {
         constexpr int CC = decltype(cc_)::value, I = decltype(i_)::value;
@@ -283,6 +292,12 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_kernel(const ConvKArgs a)
     };
 #define IC(n) std::integral_constant<int, (n)>{}
 #define SB() __builtin_amdgcn_sched_barrier(0)
+    auto u_prime = [&](auto f_) {           // positions 0 .. WINO_UD-1 of chunk 0
+        constexpr int F = decltype(f_)::value;
+        u_load(0, IC(F)); if constexpr (F + 1 < WINO_UD) u_load(0, IC(F + 1 < WINO_UD ? F + 1 : 0));
+        if constexpr (F + 2 < WINO_UD) u_load(0, IC(F + 2 < WINO_UD ? F + 2 : 0));
+        if constexpr (F + 3 < WINO_UD) u_load(0, IC(F + 3 < WINO_UD ? F + 3 : 0));
+    };
 
     // One position F of chunk `chunk` (stage cur): 4 MFMAs, with this position's share of the staging work placed
     // between them.
@@ -293,7 +308,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_kernel(const ConvKArgs a)
     //   F = 12..15     : V of chunk+1 into the idle stage
     auto slot = [&](int chunk, int cur, auto f_) {
         constexpr int F = decltype(f_)::value;
-        constexpr int R = F & 7, Q = F & 1;
+        constexpr int R = F % WINO_UR, Q = F & 1;
         auto mf = [&](auto s_) {
             constexpr int S = decltype(s_)::value;
             acc[F] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur[R][S], bq[Q][S], acc[F], 0, 0, 0);
@@ -321,9 +336,9 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_kernel(const ConvKArgs a)
         if constexpr (F >= 12 && DO_T) t_vw(cur ^ 1, IC(F >= 12 ? (F - 12) * 4 + 1 : 0));
         SB();
         mf(IC(3));
-        // ur[R] is free once this position's last MFMA is issued: position F+8 would fit; F+6 is what the ring holds
-        if constexpr (F < 10 && DO_U) u_load(chunk, IC(F < 10 ? F + 6 : 0));
-        if constexpr (F >= 10 && DO_U) u_load(chunk + 1, IC(F >= 10 ? F - 10 : 0));
+        // the ring slot of position F + WINO_UD was last read WINO_UR - WINO_UD positions ago
+        if constexpr (F + WINO_UD < 16 && DO_U) u_load(chunk, IC(F + WINO_UD < 16 ? F + WINO_UD : 0));
+        if constexpr (F + WINO_UD >= 16 && DO_U) u_load(chunk + 1, IC(F + WINO_UD >= 16 ? F + WINO_UD - 16 : 0));
         if constexpr (F == 10 && DO_T) { t_row(IC(0), IC(0)); t_row(IC(0), IC(1)); t_row(IC(0), IC(2)); t_row(IC(0), IC(3)); }
         if constexpr (F == 11 && DO_T) { t_row(IC(1), IC(0)); t_row(IC(1), IC(1)); t_row(IC(1), IC(2)); t_row(IC(1), IC(3)); }
         if constexpr (F >= 12 && DO_T) { t_vw(cur ^ 1, IC(F >= 12 ? (F - 12) * 4 + 2 : 0)); t_vw(cur ^ 1, IC(F >= 12 ? (F - 12) * 4 + 3 : 0)); }
@@ -339,7 +354,8 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_kernel(const ConvKArgs a)
         m_load(0);
         x_load(0, IC(0)); x_load(0, IC(1)); x_load(0, IC(2)); x_load(0, IC(3));
         x_load(0, IC(4)); x_load(0, IC(5)); x_load(0, IC(6)); x_load(0, IC(7));
-        u_load(0, IC(0)); u_load(0, IC(1)); u_load(0, IC(2)); u_load(0, IC(3)); u_load(0, IC(4)); u_load(0, IC(5));
+        u_prime(IC(0)); if constexpr (WINO_UD > 4) u_prime(IC(4)); if constexpr (WINO_UD > 8) u_prime(IC(WINO_UD > 8 ? 8 : 0));
+        if constexpr (WINO_UD > 12) u_prime(IC(WINO_UD > 12 ? 12 : 0));
         x_store(0, IC(0)); x_store(0, IC(1)); x_store(0, IC(2)); x_store(0, IC(3));
         x_store(0, IC(4)); x_store(0, IC(5)); x_store(0, IC(6)); x_store(0, IC(7));
         __syncthreads();
@@ -390,6 +406,82 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_kernel(const ConvKArgs a)
     // 8-byte stores need even row pitch and 8-byte aligned bases (wave-uniform)
     const bool vec = (W & 1) == 0 && ((reinterpret_cast<size_t>(a.y1) | reinterpret_cast<size_t>(a.y2) |
                                         reinterpret_cast<size_t>(a.mask_out)) & 7) == 0;
+    // Fast path (wave-uniform; every hot-path launch takes it): all 64 patches of the workgroup exist with both rows,
+    // the wave's 32 channels exist and go to one output tensor, no sigmoid.  Scalar row bases + one 32-bit lane offset:
+    // no per-store address arithmetic, no per-value predicates; a value already in y1 (accumulate_y1) is requested for
+    // all 16 rows before the first one is needed.
+    const int co_w = cg * WINO_CO + wm * 32;
+    const bool fast = !sigmoid && t0 + WINO_TILES <= ntiles && (H & 1) == 0 && co_w + 32 <= a.cout &&
+                      (co_w + 32 <= a.co1 || co_w >= a.co1) && WINO_ABL != 5;
+    if (fast) {
+        typedef __attribute__((address_space(1))) char* gwp;
+        typedef __attribute__((address_space(1))) f32x2* gw2;
+        typedef __attribute__((address_space(1))) u32x2w* gm2;
+        const bool first = co_w < a.co1;
+        const size_t plane_b = (size_t)HW * 4;
+        gwp ybase = first ? (gwp)(a.y1) + ((size_t)b * a.co1 + co_w) * plane_b
+                          : (gwp)(a.y2) + ((size_t)b * co2n + (co_w - a.co1)) * plane_b;
+        const unsigned loff = (unsigned)(4 * lh) * (unsigned)plane_b + (unsigned)p00 * 4u;
+        const unsigned wrow = (unsigned)W * 4u;
+        auto body = [&](auto add_) {
+            constexpr bool ADD = decltype(add_)::value;
+            float old[ADD ? 16 : 1][4];
+            if constexpr (ADD) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    gwp rb = ybase + (size_t)((r & 3) + 8 * (r >> 2)) * plane_b;
+                    asm volatile("" : "+s"(rb));
+                    const f32x2 v0 = *(gw2)(rb + vo(loff)), v1 = *(gw2)(rb + wrow + vo(loff));
+                    old[r][0] = v0[0]; old[r][1] = v0[1]; old[r][2] = v1[0]; old[r][3] = v1[1];
+                }
+            }
+            unsigned bits[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rowu = (r & 3) + 8 * (r >> 2);
+                float m[16];
+#pragma unroll
+                for (int f = 0; f < 16; ++f) m[f] = acc[f][r];
+                float s0[4], s1[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    s0[j] = m[j] + m[4 + j] + m[8 + j];
+                    s1[j] = m[4 + j] - m[8 + j] - m[12 + j];
+                }
+                float o[4];
+                o[0] = s0[0] + s0[1] + s0[2];
+                o[1] = s0[1] - s0[2] - s0[3];
+                o[2] = s1[0] + s1[1] + s1[2];
+                o[3] = s1[1] - s1[2] - s1[3];
+                const float badd = BIASL[wm * 32 + rowu + 4 * lh];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float u = fmaf(o[q], sc, badd);
+                    o[q] = fmaxf(u, slope * u);          // none (slope 1) / leaky_relu (0.01): bitwise scm_act_sel
+                    bits[q] |= (o[q] > 0.f ? 1u : 0u) << (rowu + 4 * lh);
+                    if constexpr (ADD) o[q] += old[r][q];
+                }
+                gwp rb = ybase + (size_t)rowu * plane_b;
+                asm volatile("" : "+s"(rb));
+                f32x2 v0 = {o[0], o[1]}, v1 = {o[2], o[3]};
+                *(gw2)(rb + vo(loff)) = v0;
+                *(gw2)(rb + wrow + vo(loff)) = v1;
+            }
+            if (a.mask_out) {         // wave-uniform: the 1-bit leaky-relu gate of this wave's 32 channels
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bits[q] |= __shfl_xor(bits[q], 32);
+                const int nw = (a.cout + 31) >> 5;
+                gwp mrow = (gwp)(a.mask_out) + ((size_t)b * nw + (cg * 2 + wm)) * plane_b;
+                if (lh == 0) {
+                    u32x2w v0 = {bits[0], bits[1]}, v1 = {bits[2], bits[3]};
+                    *(gm2)(mrow + p00 * 4) = v0;
+                    *(gm2)(mrow + wrow + p00 * 4) = v1;
+                }
+            }
+        };
+        if (a.acc_y1 && first) body(std::true_type{});
+        else body(std::false_type{});
+    } else {
     unsigned bits[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -416,7 +508,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_kernel(const ConvKArgs a)
             o[q] = sigmoid ? scm_sigmoid(u) : scm_act_sel(u, slope);
             bits[q] |= (o[q] > 0.f ? 1u : 0u) << row;
         }
-        if (co < a.cout && tvalid) {
+        if (co < a.cout && tvalid && WINO_ABL != 5) {
             const bool first = co < a.co1;
             float* dst = (first ? a.y1 + ((size_t)b * a.co1 + co) * HW
                                 : a.y2 + ((size_t)b * co2n + (co - a.co1)) * HW) + p00;
@@ -458,6 +550,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_kernel(const ConvKArgs a)
                 }
             }
         }
+    }
     }
 #ifdef WINO_TIMING
     __builtin_amdgcn_s_waitcnt(0);
@@ -560,7 +653,7 @@ static inline int wino_plane(int H, int W) {
     const int tcw = W / 2, trh = (H + 1) / 2;
     int trows = (WINO_TILES % tcw == 0) ? WINO_TILES / tcw : (WINO_TILES + tcw - 2) / tcw + 1;
     if (trows > trh) trows = trh;
-    return (2 * trows + 2) * (W + 4);
+    return (2 * trows + 2) * (W + 6);
 }
 
 extern "C" int scm_conv3x3_wino_serves(int H, int W) {
@@ -599,8 +692,10 @@ extern "C" int scm_conv3x3_wino(const scm_conv3x3_desc* d, void* stream) {
     SCM_REQUIRE(!d->gate_mask_out || k.mask_out, "scm_conv3x3_wino: gate_mask_out needs act == LRELU and cout > 32");
     SCM_REQUIRE(d->c2 == 0 || (d->c1 & 7) == 0, "scm_conv3x3_wino: c1 must be a multiple of 8 when x2 is given (c1=%d)", d->c1);
     SCM_REQUIRE(((reinterpret_cast<size_t>(d->x1) | reinterpret_cast<size_t>(d->x2) | reinterpret_cast<size_t>(d->gate1) |
-                  reinterpret_cast<size_t>(d->gate2) | reinterpret_cast<size_t>(d->gate_mask_in)) & 7) == 0,
-                "scm_conv3x3_wino: input tensors must be 8-byte aligned");
+                  reinterpret_cast<size_t>(d->gate2) | reinterpret_cast<size_t>(d->gate_mask_in) |
+                  reinterpret_cast<size_t>(d->y1) | reinterpret_cast<size_t>(d->y2) |
+                  reinterpret_cast<size_t>(d->gate_mask_out)) & 7) == 0,
+                "scm_conv3x3_wino: tensors must be 8-byte aligned");
     const int ntiles = ((d->H + 1) / 2) * (d->W / 2);
     k.tiles_per_img = (ntiles + WINO_TILES - 1) / WINO_TILES;
     k.plane = wino_plane(d->H, d->W);
