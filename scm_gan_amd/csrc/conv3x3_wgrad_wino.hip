@@ -26,6 +26,17 @@
 
 typedef unsigned u32x4q __attribute__((ext_vector_type(4)));
 
+// Phase clock / ablation switches for tools/exp/ww_phases.hip (compiled in only with -DWW_TIMING=<workgroup>)
+#ifdef WW_TIMING
+__device__ unsigned long long ww_ticks[4];
+#define WW_TICK(i) do { const unsigned long long t_ = clock64(); t_acc[i] += t_ - t_last; t_last = t_; } while (0)
+#else
+#define WW_TICK(i)
+#endif
+#ifndef WW_ABL
+#define WW_ABL 0
+#endif
+
 // GATED: 0 none, 1 gate tensor (act' from the saved output), 2 1-bit leaky-relu mask.  PADC: circular padding.
 // EDGE: some patches / rows / output channels of a chunk may not exist (H odd, patch row not a multiple of 8 patches,
 // cout not a multiple of 64): their output gradient is forced to zero.
@@ -84,108 +95,146 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wgrad_wino_kernel(const WgradK
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
 
-    // ---- registers that live across the K loop
-    float xr[4][6];         // input rows 2*ty-1 .. 2*ty+2, columns ix0-1 .. ix0+4 of the NEXT chunk's patch pair
-    float dr[2][4];         // output-gradient rows 2*ty, 2*ty+1, columns ix0 .. ix0+3
-    float gr[GATED == 1 ? 2 : 1][4];
-    unsigned mr[GATED == 2 ? 2 : 1][4];
+    // ---- registers that live across the K loop.  Chunk c's elements live in register set c & 1: while chunk k's
+    // MFMAs run, chunk k+1 (set (k+1) & 1, requested a whole iteration ago) is transformed and chunk k+2 is requested
+    // into set k & 1 -- a full chunk of MFMAs between a request and its first use (these are gathers: a quarter-wave
+    // per row segment, mostly beyond L2).  The K loop is unrolled by two so that every register index is static.
+    float xr[2][4][6];      // input rows 2*ty-1 .. 2*ty+2, columns ix0-1 .. ix0+4 of a patch pair
+    float dr[2][2][4];      // output-gradient rows 2*ty, 2*ty+1, columns ix0 .. ix0+3
+    float gr[2][GATED == 1 ? 2 : 1][4];
+    unsigned mr[2][GATED == 2 ? 2 : 1][4];
+    float x_e[2][4], x_e2[2][EDGE ? 4 : 1];   // the outer column(s) of each row as loaded (placed by ld_xfix)
+    int l_ty[2] = {0, 0};
+    float l_em[2] = {1.f, 1.f}, l_em2[2] = {1.f, 1.f};
+    unsigned l_xe = 0, l_xe2 = 0, l_xm = 0, l_dm = 0, l_mm = 0;
     float vx[2][16], vd[2][16];
     float aq[2][4], bq[2][4];
     float csum = 0.f;
+    const bool q0 = q == 0, q3 = q == 3;
+#define IC(n) std::integral_constant<int, (n)>{}
+#define SB() __builtin_amdgcn_sched_barrier(0)
 
     // chunk k of the band: patch row ty = tr0 + k / nchr, patches 8*cx .. 8*cx+7, cx = k % nchr.  The loads of a chunk
-    // past the end re-read the last chunk (never used).  ld_setup fixes the chunk's lane offsets, ld_xrow / ld_drow
-    // request one input / output-gradient row each.
-    int l_ty = 0;
-    unsigned l_xl = 0, l_xm = 0, l_xr = 0, l_dm = 0, l_mm = 0;
-    float l_lm = 1.f, l_rm = 1.f;
-    auto ld_setup = [&](int k) {
+    // past the end re-read the last chunk (never used).  ld_setup fixes the chunk's lane offsets, ld_xrow / ld_xedge /
+    // ld_drow request one row each into register set P.
+    auto ld_setup = [&](int k, auto p_) {
+        constexpr int P = decltype(p_)::value;
         const int kc = k < nchunk ? k : (nchunk > 0 ? nchunk - 1 : 0);
-        l_ty = tr0 + kc / nchr;
+        l_ty[P] = tr0 + kc / nchr;
         const int cx = kc - (kc / nchr) * nchr;
         const int ix0 = 16 * cx + 4 * q;                 // first image column of the pair's outputs
         const int ixm = ix0 < W ? ix0 : W - 4;           // (a pair past the row end reads the last one: finite data)
-        int ixl = ixm - 1, ixr = ixm + 4;
-        ixl = ixl < 0 ? (PADC ? W - 1 : 0) : ixl;
-        ixr = ixr >= W ? (PADC ? 0 : W - 1) : ixr;
-        if constexpr (!PADC) {
-            l_lm = ixm == 0 ? 0.f : 1.f;
-            l_rm = ixm + 4 >= W ? 0.f : 1.f;
+        // Of the pair's six columns the middle four are one aligned 16-byte load; the outer two are the neighbouring
+        // pair's edge columns (lanes q-1 / q+1 of the quad: a DPP move each) -- except the chunk's own outer columns,
+        // 16*cx - 1 for pair 0 and 16*cx + 16 for pair 3, which those two lanes fetch with ONE 4-byte load per row.
+        // (EDGE builds -- a row may end inside a chunk -- load both outer columns of every pair instead)
+        int ixe = EDGE ? ixm - 1 : (q3 ? 16 * cx + 16 : 16 * cx - 1);
+        const bool ein = ixe >= 0 && ixe < W;
+        ixe = ixe < 0 ? (PADC ? W - 1 : 0) : (ixe >= W ? (PADC ? 0 : W - 1) : ixe);
+        if constexpr (!PADC) l_em[P] = ein ? 1.f : 0.f;
+        if constexpr (EDGE) {
+            int ixr = ixm + 4;
+            if constexpr (!PADC) l_em2[P] = ixr < W ? 1.f : 0.f;
+            ixr = ixr >= W ? (PADC ? 0 : W - 1) : ixr;
+            l_xe2 = xch + ixr * 4;
         }
-        l_xl = xch + ixl * 4; l_xm = xch + ixm * 4; l_xr = xch + ixr * 4;
+        l_xe = xch + ixe * 4; l_xm = xch + ixm * 4;
         l_dm = dch + ixm * 4; l_mm = mch + ixm * 4;
     };
-    auto ld_xrow = [&](auto i_) {
-        constexpr int I = decltype(i_)::value;
-        int iy = 2 * l_ty - 1 + I;
-        float ym = 1.f;
+    auto xrow_base = [&](int ty, int i) {
+        int iy = 2 * ty - 1 + i;
         if (PADC) iy = iy < 0 ? iy + H : (iy >= H ? iy - H : iy);
-        else { ym = (iy >= 0 && iy < H) ? 1.f : 0.f; iy = iy < 0 ? 0 : (iy >= H ? H - 1 : iy); }
-        gcp row = xb + (size_t)iy * (W * 4);
-        asm volatile("" : "+s"(row));
-        const f32x4 m = *(gfp4)(row + vo(l_xm));
-        xr[I][0] = *(gfp)(row + vo(l_xl));
-        xr[I][1] = m[0]; xr[I][2] = m[1]; xr[I][3] = m[2]; xr[I][4] = m[3];
-        xr[I][5] = *(gfp)(row + vo(l_xr));
-        if constexpr (!PADC) {
-            xr[I][0] *= ym * l_lm; xr[I][5] *= ym * l_rm;
-            xr[I][1] *= ym; xr[I][2] *= ym; xr[I][3] *= ym; xr[I][4] *= ym;
-        }
+        else iy = iy < 0 ? 0 : (iy >= H ? H - 1 : iy);
+        return xb + (size_t)iy * (W * 4);
     };
-    auto ld_drow = [&](auto i_) {
-        constexpr int I = decltype(i_)::value;
-        int oy = 2 * l_ty + I;
+    auto ld_xrow = [&](auto p_, auto i_) {
+        constexpr int P = decltype(p_)::value, I = decltype(i_)::value;
+        gcp row = xrow_base(l_ty[P], I);
+        const f32x4 m = *(gfp4)(row + vo(l_xm));
+        xr[P][I][1] = m[0]; xr[P][I][2] = m[1]; xr[P][I][3] = m[2]; xr[P][I][4] = m[3];
+    };
+    auto ld_xedge = [&](auto p_, auto i_) {
+        constexpr int P = decltype(p_)::value, I = decltype(i_)::value;
+        gcp row = xrow_base(l_ty[P], I);
+        x_e[P][I] = *(gfp)(row + vo(l_xe));
+        if constexpr (EDGE) x_e2[P][I] = *(gfp)(row + vo(l_xe2));
+    };
+    // after the loads have landed: outer columns from the quad neighbours / the edge load, zero padding applied
+    auto ld_xfix = [&](auto p_, auto i_) {
+        constexpr int P = decltype(p_)::value, I = decltype(i_)::value;
+        float e = x_e[P][I], e2 = EDGE ? x_e2[P][EDGE ? I : 0] : 0.f;
+        if constexpr (!PADC) {
+            const int iy = 2 * l_ty[P] - 1 + I;
+            const float ym = (iy >= 0 && iy < H) ? 1.f : 0.f;
+            e *= ym * l_em[P];
+            if constexpr (EDGE) e2 *= ym * l_em2[P];
+            xr[P][I][1] *= ym; xr[P][I][2] *= ym; xr[P][I][3] *= ym; xr[P][I][4] *= ym;
+        }
+        if constexpr (EDGE) {
+            xr[P][I][0] = e; xr[P][I][5] = e2;
+            return;
+        }
+        // quad_perm [0,0,1,2] = 0x90: lane q reads lane q-1;  [1,2,3,3] = 0xF9: lane q reads lane q+1
+        const float fl = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, xr[P][I][4]), 0x90, 0xF, 0xF, true));
+        const float fr = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, xr[P][I][1]), 0xF9, 0xF, 0xF, true));
+        xr[P][I][0] = q0 ? e : fl;
+        xr[P][I][5] = q3 ? e : fr;
+    };
+    auto ld_drow = [&](auto p_, auto i_) {
+        constexpr int P = decltype(p_)::value, I = decltype(i_)::value;
+        int oy = 2 * l_ty[P] + I;
         oy = oy < H ? oy : H - 1;
         const size_t ro = (size_t)oy * (W * 4);
         gcp drow = db + ro;
-        asm volatile("" : "+s"(drow));
         const f32x4 d = *(gfp4)(drow + vo(l_dm));
-        dr[I][0] = d[0]; dr[I][1] = d[1]; dr[I][2] = d[2]; dr[I][3] = d[3];
+        dr[P][I][0] = d[0]; dr[P][I][1] = d[1]; dr[P][I][2] = d[2]; dr[P][I][3] = d[3];
         if constexpr (GATED == 1) {
             gcp grow = gb + ro;
-            asm volatile("" : "+s"(grow));
             const f32x4 g = *(gfp4)(grow + vo(l_dm));
-            gr[I][0] = g[0]; gr[I][1] = g[1]; gr[I][2] = g[2]; gr[I][3] = g[3];
+            gr[P][I][0] = g[0]; gr[P][I][1] = g[1]; gr[P][I][2] = g[2]; gr[P][I][3] = g[3];
         }
         if constexpr (GATED == 2) {
             gcp mrow = mb + ro;
-            asm volatile("" : "+s"(mrow));
             const u32x4q m = *(gup4)(mrow + vo(l_mm));
-            mr[I][0] = m[0]; mr[I][1] = m[1]; mr[I][2] = m[2]; mr[I][3] = m[3];
+            mr[P][I][0] = m[0]; mr[P][I][1] = m[1]; mr[P][I][2] = m[2]; mr[P][I][3] = m[3];
         }
     };
-#define IC(n) std::integral_constant<int, (n)>{}
-    auto load_chunk = [&](int k) {
-        ld_setup(k);
-        ld_xrow(IC(0)); ld_xrow(IC(1)); ld_xrow(IC(2)); ld_xrow(IC(3));
-        ld_drow(IC(0)); ld_drow(IC(1));
+    auto load_chunk = [&](int k, auto p_) {
+        ld_setup(k, p_);
+        ld_xrow(p_, IC(0)); ld_xrow(p_, IC(1)); ld_xrow(p_, IC(2)); ld_xrow(p_, IC(3));
+        ld_xedge(p_, IC(0)); ld_xedge(p_, IC(1)); ld_xedge(p_, IC(2)); ld_xedge(p_, IC(3));
+        ld_drow(p_, IC(0)); ld_drow(p_, IC(1));
     };
-    // gate, validity and channel sum of the loaded output gradient (chunk k)
-    auto gate_chunk = [&](int k) {
+    auto fix_chunk = [&](auto p_) { ld_xfix(p_, IC(0)); ld_xfix(p_, IC(1)); ld_xfix(p_, IC(2)); ld_xfix(p_, IC(3)); };
+    // gate, validity and channel sum of the loaded output gradient (chunk k, register set P)
+    auto gate_chunk = [&](int k, auto p_) {
+        constexpr int P = decltype(p_)::value;
         const bool real = k < nchunk;
+        const float realf = real ? 1.f : 0.f;
         const int kc = real ? k : (nchunk > 0 ? nchunk - 1 : 0);
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float v = dr[i][j];
-                if constexpr (GATED == 1) v *= scm_act_grad_from_out(gr[i][j], a.gate_act);
-                if constexpr (GATED == 2) v = (mr[i][j] & mbit) ? v : 0.01f * v;
+                float v = dr[P][i][j];
+                if constexpr (GATED == 1) v *= scm_act_grad_from_out(gr[P][i][j], a.gate_act);
+                if constexpr (GATED == 2) v = (mr[P][i][j] & mbit) ? v : 0.01f * v;
                 if constexpr (EDGE) {
                     const int ty = tr0 + kc / nchr, cx = kc - (kc / nchr) * nchr;
                     const bool ok = (2 * ty + i < H) && (16 * cx + 4 * q + j < W);
                     v = ok ? v * chv : 0.f;
                 }
-                dr[i][j] = v;
+                v *= realf;
+                dr[P][i][j] = v;
                 s += v;
             }
-        csum += real ? s : 0.f;
+        csum += s;
     };
     // A dY A^T without the signs of its fourth row / column (put back in the epilogue), patch T of the pair
-    auto dy_xform = [&](auto t_) {
-        constexpr int T = decltype(t_)::value;
-        const float p = dr[0][2 * T], qq = dr[0][2 * T + 1], r = dr[1][2 * T], s = dr[1][2 * T + 1];
+    auto dy_xform = [&](auto p_, auto t_) {
+        constexpr int P = decltype(p_)::value, T = decltype(t_)::value;
+        const float p = dr[P][0][2 * T], qq = dr[P][0][2 * T + 1], r = dr[P][1][2 * T], s = dr[P][1][2 * T + 1];
         const float r1a = p + r, r1b = qq + s, r2a = p - r, r2b = qq - s;
         vd[T][0] = p;   vd[T][1] = p + qq;     vd[T][2] = p - qq;     vd[T][3] = qq;
         vd[T][4] = r1a; vd[T][5] = r1a + r1b;  vd[T][6] = r1a - r1b;  vd[T][7] = r1b;
@@ -193,101 +242,117 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wgrad_wino_kernel(const WgradK
         vd[T][12] = r;  vd[T][13] = r + s;     vd[T][14] = r - s;     vd[T][15] = s;
     };
     // B^T d B: along y for column J of the pair's 6 columns (in place), then along x for patch T
-    auto x_vert = [&](auto j_) {
-        constexpr int J = decltype(j_)::value;
-        const float d0 = xr[0][J], d1 = xr[1][J], d2 = xr[2][J], d3 = xr[3][J];
-        xr[0][J] = d0 - d2; xr[1][J] = d1 + d2; xr[2][J] = d2 - d1; xr[3][J] = d1 - d3;
+    auto x_vert = [&](auto p_, auto j_) {
+        constexpr int P = decltype(p_)::value, J = decltype(j_)::value;
+        const float d0 = xr[P][0][J], d1 = xr[P][1][J], d2 = xr[P][2][J], d3 = xr[P][3][J];
+        xr[P][0][J] = d0 - d2; xr[P][1][J] = d1 + d2; xr[P][2][J] = d2 - d1; xr[P][3][J] = d1 - d3;
     };
-    auto x_horz = [&](auto t_, auto i_) {
-        constexpr int T = decltype(t_)::value, I = decltype(i_)::value;
-        const float c0 = xr[I][2 * T], c1 = xr[I][2 * T + 1], c2 = xr[I][2 * T + 2], c3 = xr[I][2 * T + 3];
+    auto x_horz = [&](auto p_, auto t_, auto i_) {
+        constexpr int P = decltype(p_)::value, T = decltype(t_)::value, I = decltype(i_)::value;
+        const float c0 = xr[P][I][2 * T], c1 = xr[P][I][2 * T + 1], c2 = xr[P][I][2 * T + 2], c3 = xr[P][I][2 * T + 3];
         vx[T][4 * I + 0] = c0 - c2; vx[T][4 * I + 1] = c1 + c2; vx[T][4 * I + 2] = c2 - c1; vx[T][4 * I + 3] = c1 - c3;
     };
     // the pair's two patches of position F -> operand image [F][half][channel][step]: patch 2*q + t of the chunk is
     // MFMA k index (half = q >> 1, step = 2 * (q & 1) + t)
     const int wofs = ((q >> 1) * 64 + ch) * 4 + (q & 1) * 2;
-    auto dy_write = [&](int st, auto f_) {
-        constexpr int F = decltype(f_)::value;
+    auto dy_write = [&](auto st_, auto f_) {
+        constexpr int ST = decltype(st_)::value, F = decltype(f_)::value;
         f32x2 o; o[0] = vd[0][F]; o[1] = vd[1][F];
-        *reinterpret_cast<f32x2*>(DYL + st * WW_SLAB + F * 512 + wofs) = o;
+        *reinterpret_cast<f32x2*>(DYL + ST * WW_SLAB + F * 512 + wofs) = o;
     };
-    auto x_write = [&](int st, auto f_) {
-        constexpr int F = decltype(f_)::value;
+    auto x_write = [&](auto st_, auto f_) {
+        constexpr int ST = decltype(st_)::value, F = decltype(f_)::value;
         f32x2 o; o[0] = vx[0][F]; o[1] = vx[1][F];
-        *reinterpret_cast<f32x2*>(VL + st * WW_SLAB + F * 512 + wofs) = o;
+        *reinterpret_cast<f32x2*>(VL + ST * WW_SLAB + F * 512 + wofs) = o;
     };
-    auto ab_read = [&](int st, auto f_) {
-        constexpr int F = decltype(f_)::value;
-        const f32x4 ta = *reinterpret_cast<const f32x4*>(DYL + st * WW_SLAB + F * 512 + (lh * 64 + wm * 32 + l31) * 4);
-        const f32x4 tb = *reinterpret_cast<const f32x4*>(VL + st * WW_SLAB + F * 512 + (lh * 64 + wn * 32 + l31) * 4);
+    auto ab_read = [&](auto st_, auto f_) {
+        constexpr int ST = decltype(st_)::value, F = decltype(f_)::value;
+        const f32x4 ta = *reinterpret_cast<const f32x4*>(DYL + ST * WW_SLAB + F * 512 + (lh * 64 + wm * 32 + l31) * 4);
+        const f32x4 tb = *reinterpret_cast<const f32x4*>(VL + ST * WW_SLAB + F * 512 + (lh * 64 + wn * 32 + l31) * 4);
         aq[F & 1][0] = ta[0]; aq[F & 1][1] = ta[1]; aq[F & 1][2] = ta[2]; aq[F & 1][3] = ta[3];
         bq[F & 1][0] = tb[0]; bq[F & 1][1] = tb[1]; bq[F & 1][2] = tb[2]; bq[F & 1][3] = tb[3];
     };
-#define SB() __builtin_amdgcn_sched_barrier(0)
-    // One position F of chunk k (stage cur): 4 MFMAs; the transform of chunk k+1 (in registers) and the loads of chunk
-    // k+2 are dealt out behind them.
-    auto slot = [&](int k, int cur, auto f_) {
-        constexpr int F = decltype(f_)::value;
+    // One position F of chunk k (LDS stage and register parity P = k & 1): 4 MFMAs; behind them the transform of
+    // chunk k+1 (register set P ^ 1) into stage P ^ 1 and the requests of chunk k+2 into register set P, one per MFMA.
+    auto slot = [&](int k, auto p_, auto f_) {
+        constexpr int P = decltype(p_)::value, F = decltype(f_)::value;
         auto mf = [&](auto s_) {
             constexpr int S = decltype(s_)::value;
             acc[F] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[F & 1][S], bq[F & 1][S], acc[F], 0, 0, 0);
         };
+        constexpr bool DO_L = WW_ABL < 1, DO_T = WW_ABL < 2, DO_W = WW_ABL < 3, DO_R = WW_ABL < 4;
+        constexpr auto PN = IC(P ^ 1);
         mf(IC(0));
-        if constexpr (F < 15) ab_read(cur, IC(F < 15 ? F + 1 : 0));
+        if constexpr (F < 15 && DO_R) ab_read(p_, IC(F < 15 ? F + 1 : 0));
+        if constexpr (F == 0 && DO_L) { ld_setup(k + 2, p_); ld_xrow(p_, IC(0)); }
+        if constexpr (F == 1 && DO_L) ld_xrow(p_, IC(2));
+        if constexpr (F == 2 && DO_L) ld_xedge(p_, IC(0));
+        if constexpr (F == 3 && DO_L) ld_xedge(p_, IC(2));
+        if constexpr (F == 4 && DO_L) ld_drow(p_, IC(0));
         SB();
         mf(IC(1));
-        if constexpr (F == 0) gate_chunk(k + 1);
-        if constexpr (F == 1) { dy_xform(IC(0)); dy_xform(IC(1)); }
-        if constexpr (F == 2) { x_vert(IC(0)); x_vert(IC(1)); x_vert(IC(2)); }
-        if constexpr (F == 3) { x_vert(IC(3)); x_vert(IC(4)); x_vert(IC(5)); }
-        if constexpr (F == 4) { x_horz(IC(0), IC(0)); x_horz(IC(0), IC(1)); }
-        if constexpr (F == 5) { x_horz(IC(0), IC(2)); x_horz(IC(0), IC(3)); }
-        if constexpr (F == 6) { x_horz(IC(1), IC(0)); x_horz(IC(1), IC(1)); }
-        if constexpr (F == 7) { x_horz(IC(1), IC(2)); x_horz(IC(1), IC(3)); }
-        if constexpr (F >= 8) { dy_write(cur ^ 1, IC(F >= 8 ? 2 * (F - 8) : 0)); x_write(cur ^ 1, IC(F >= 8 ? 2 * (F - 8) : 0)); }
+        if constexpr (F == 0 && DO_T) gate_chunk(k + 1, PN);
+        if constexpr (F == 1 && DO_T) { dy_xform(PN, IC(0)); dy_xform(PN, IC(1)); fix_chunk(PN); }
+        if constexpr (F == 2 && DO_T) { x_vert(PN, IC(0)); x_vert(PN, IC(1)); x_vert(PN, IC(2)); }
+        if constexpr (F == 3 && DO_T) { x_vert(PN, IC(3)); x_vert(PN, IC(4)); x_vert(PN, IC(5)); }
+        if constexpr (F == 4 && DO_T) { x_horz(PN, IC(0), IC(0)); x_horz(PN, IC(0), IC(1)); }
+        if constexpr (F == 5 && DO_T) { x_horz(PN, IC(0), IC(2)); x_horz(PN, IC(0), IC(3)); }
+        if constexpr (F == 6 && DO_T) { x_horz(PN, IC(1), IC(0)); x_horz(PN, IC(1), IC(1)); }
+        if constexpr (F == 7 && DO_T) { x_horz(PN, IC(1), IC(2)); x_horz(PN, IC(1), IC(3)); }
+        if constexpr (F >= 8 && DO_W) { dy_write(PN, IC(F >= 8 ? 2 * (F - 8) : 0)); x_write(PN, IC(F >= 8 ? 2 * (F - 8) : 0)); }
         SB();
         mf(IC(2));
-        if constexpr (F >= 8) { dy_write(cur ^ 1, IC(F >= 8 ? 2 * (F - 8) + 1 : 0)); x_write(cur ^ 1, IC(F >= 8 ? 2 * (F - 8) + 1 : 0)); }
+        if constexpr (F >= 8 && DO_W) { dy_write(PN, IC(F >= 8 ? 2 * (F - 8) + 1 : 0)); x_write(PN, IC(F >= 8 ? 2 * (F - 8) + 1 : 0)); }
         SB();
         mf(IC(3));
-        // the registers of chunk k+1 are consumed by position 7: chunk k+2 is requested into them, a row per position
-        if constexpr (F == 8) { ld_setup(k + 2); ld_xrow(IC(0)); }
-        if constexpr (F == 9) ld_xrow(IC(1));
-        if constexpr (F == 10) ld_xrow(IC(2));
-        if constexpr (F == 11) ld_xrow(IC(3));
-        if constexpr (F == 12) ld_drow(IC(0));
-        if constexpr (F == 13) ld_drow(IC(1));
+        if constexpr (F == 0 && DO_L) ld_xrow(p_, IC(1));
+        if constexpr (F == 1 && DO_L) ld_xrow(p_, IC(3));
+        if constexpr (F == 2 && DO_L) ld_xedge(p_, IC(1));
+        if constexpr (F == 3 && DO_L) ld_xedge(p_, IC(3));
+        if constexpr (F == 4 && DO_L) ld_drow(p_, IC(1));
+        SB();
+    };
+    auto chunk_body = [&](int k, auto p_) {
+        if (WW_ABL < 4) ab_read(p_, IC(0));
+        SB();
+        slot(k, p_, IC(0)); slot(k, p_, IC(1)); slot(k, p_, IC(2)); slot(k, p_, IC(3));
+        slot(k, p_, IC(4)); slot(k, p_, IC(5)); slot(k, p_, IC(6)); slot(k, p_, IC(7));
+        slot(k, p_, IC(8)); slot(k, p_, IC(9)); slot(k, p_, IC(10)); slot(k, p_, IC(11));
+        slot(k, p_, IC(12)); slot(k, p_, IC(13)); slot(k, p_, IC(14)); slot(k, p_, IC(15));
+        __syncthreads();            // the other stage holds chunk k+1; every wave is done with this one
         SB();
     };
 
-    // ---- prologue: chunk 0 transformed into stage 0, chunk 1 in the registers
-    load_chunk(0);
-    gate_chunk(0);
-    dy_xform(IC(0)); dy_xform(IC(1));
-    x_vert(IC(0)); x_vert(IC(1)); x_vert(IC(2)); x_vert(IC(3)); x_vert(IC(4)); x_vert(IC(5));
-    x_horz(IC(0), IC(0)); x_horz(IC(0), IC(1)); x_horz(IC(0), IC(2)); x_horz(IC(0), IC(3));
-    x_horz(IC(1), IC(0)); x_horz(IC(1), IC(1)); x_horz(IC(1), IC(2)); x_horz(IC(1), IC(3));
-    load_chunk(1);
-    dy_write(0, IC(0)); dy_write(0, IC(1)); dy_write(0, IC(2)); dy_write(0, IC(3)); dy_write(0, IC(4)); dy_write(0, IC(5));
-    dy_write(0, IC(6)); dy_write(0, IC(7)); dy_write(0, IC(8)); dy_write(0, IC(9)); dy_write(0, IC(10)); dy_write(0, IC(11));
-    dy_write(0, IC(12)); dy_write(0, IC(13)); dy_write(0, IC(14)); dy_write(0, IC(15));
-    x_write(0, IC(0)); x_write(0, IC(1)); x_write(0, IC(2)); x_write(0, IC(3)); x_write(0, IC(4)); x_write(0, IC(5));
-    x_write(0, IC(6)); x_write(0, IC(7)); x_write(0, IC(8)); x_write(0, IC(9)); x_write(0, IC(10)); x_write(0, IC(11));
-    x_write(0, IC(12)); x_write(0, IC(13)); x_write(0, IC(14)); x_write(0, IC(15));
+#ifdef WW_TIMING
+    unsigned long long t_acc[4] = {0, 0, 0, 0};
+    unsigned long long t_last = clock64();
+#endif
+    // ---- prologue: chunk 0 (register set 0) transformed into stage 0, chunk 1 requested into set 1
+    load_chunk(0, IC(0));
+    load_chunk(1, IC(1));
+    fix_chunk(IC(0));
+    gate_chunk(0, IC(0));
+    dy_xform(IC(0), IC(0)); dy_xform(IC(0), IC(1));
+    x_vert(IC(0), IC(0)); x_vert(IC(0), IC(1)); x_vert(IC(0), IC(2)); x_vert(IC(0), IC(3)); x_vert(IC(0), IC(4)); x_vert(IC(0), IC(5));
+    x_horz(IC(0), IC(0), IC(0)); x_horz(IC(0), IC(0), IC(1)); x_horz(IC(0), IC(0), IC(2)); x_horz(IC(0), IC(0), IC(3));
+    x_horz(IC(0), IC(1), IC(0)); x_horz(IC(0), IC(1), IC(1)); x_horz(IC(0), IC(1), IC(2)); x_horz(IC(0), IC(1), IC(3));
+    dy_write(IC(0), IC(0)); dy_write(IC(0), IC(1)); dy_write(IC(0), IC(2)); dy_write(IC(0), IC(3)); dy_write(IC(0), IC(4)); dy_write(IC(0), IC(5));
+    dy_write(IC(0), IC(6)); dy_write(IC(0), IC(7)); dy_write(IC(0), IC(8)); dy_write(IC(0), IC(9)); dy_write(IC(0), IC(10)); dy_write(IC(0), IC(11));
+    dy_write(IC(0), IC(12)); dy_write(IC(0), IC(13)); dy_write(IC(0), IC(14)); dy_write(IC(0), IC(15));
+    x_write(IC(0), IC(0)); x_write(IC(0), IC(1)); x_write(IC(0), IC(2)); x_write(IC(0), IC(3)); x_write(IC(0), IC(4)); x_write(IC(0), IC(5));
+    x_write(IC(0), IC(6)); x_write(IC(0), IC(7)); x_write(IC(0), IC(8)); x_write(IC(0), IC(9)); x_write(IC(0), IC(10)); x_write(IC(0), IC(11));
+    x_write(IC(0), IC(12)); x_write(IC(0), IC(13)); x_write(IC(0), IC(14)); x_write(IC(0), IC(15));
     __syncthreads();
-    for (int k = 0; k < nchunk; ++k) {
-        const int cur = k & 1;
-        ab_read(cur, IC(0));
-        SB();
-        slot(k, cur, IC(0)); slot(k, cur, IC(1)); slot(k, cur, IC(2)); slot(k, cur, IC(3));
-        slot(k, cur, IC(4)); slot(k, cur, IC(5)); slot(k, cur, IC(6)); slot(k, cur, IC(7));
-        slot(k, cur, IC(8)); slot(k, cur, IC(9)); slot(k, cur, IC(10)); slot(k, cur, IC(11));
-        slot(k, cur, IC(12)); slot(k, cur, IC(13)); slot(k, cur, IC(14)); slot(k, cur, IC(15));
-        __syncthreads();            // stage cur ^ 1 holds chunk k+1; every wave is done with stage cur
-        SB();
+    WW_TICK(0);
+    // (always whole pairs of chunks -- the accumulators must not cross a conditional: a chunk past the end has its
+    // output gradient forced to zero in gate_chunk and adds nothing)
+    for (int k = 0; k < nchunk; k += 2) {
+        chunk_body(k, IC(0));
+        chunk_body(k + 1, IC(1));
     }
 #undef IC
 #undef SB
+    WW_TICK(1);
 
     // ---- epilogue: signs of A's fourth row / column, dg = G^T dU G, 3x3 partials of this split
     //   G^T = [1 .5 .5 0; 0 .5 -.5 0; 0 .5 .5 1]
@@ -328,6 +393,12 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wgrad_wino_kernel(const WgradK
         s += __shfl_xor(s, 2);
         if (q == 0 && co < a.cout) a.csum_part[(size_t)split * a.cout + co] = s;
     }
+#ifdef WW_TIMING
+    __builtin_amdgcn_s_waitcnt(0);
+    WW_TICK(2);
+    if (blockIdx.x == WW_TIMING && blockIdx.y == 0 && tid == 0)
+        for (int i = 0; i < 4; ++i) ww_ticks[i] = t_acc[i];
+#endif
 }
 
 // ------------------------------------------------------------------ host
