@@ -1,5 +1,6 @@
 """128->128, B=64, 64x64 launches of the hot kernels as the training step issues them (1-bit gate mask on):
-fp32 forward / gated dgrad / wgrad, their fp32-on-the-bf16-pipe (fp32x3) and 16-bit-operand forms, on preallocated buffers (for rocprofv3 --pmc passes)."""
+fp32 forward / gated dgrad / wgrad in the default Winograd form and in the direct form, their fp32-on-the-bf16-pipe (fp32x3)
+and 16-bit-operand forms, on preallocated buffers (for rocprofv3 --pmc passes)."""
 import ctypes, sys, torch
 sys.path.insert(0, '.')
 from scm_gan_amd import _lib as L, ops
@@ -14,8 +15,9 @@ pf, cf = ctypes.c_size_t(), ctypes.c_size_t()
 lib.scm_conv3x3_wgrad_workspace(B, H, W, C, C, ctypes.byref(pf), ctypes.byref(cf))
 part = torch.empty(pf.value, device='cuda'); cws = torch.empty(cf.value, device='cuda')
 dw = torch.empty_like(w); db = torch.empty(C, device='cuda')
-for mode in ('fp32', 'fp32x3', 'fp16'):
-    ops.set_compute_precision(mode)
+for mode in ('fp32', 'fp32-direct', 'fp32x3', 'fp16'):
+    ops.set_conv_algo('direct' if mode == 'fp32-direct' else 'winograd')
+    ops.set_compute_precision('fp32' if mode == 'fp32-direct' else mode)
     fp, dp, fprec, dprec = ops.pack_conv3x3(w, C, C)[:4]
     mask = torch.zeros(B, C // 32, H, W, device='cuda', dtype=torch.int32)
     for _ in range(3):
@@ -23,13 +25,16 @@ for mode in ('fp32', 'fp32x3', 'fp16'):
         dx, _ = ops._conv3x3_raw(gy, None, y, None, ops.ACT_LRELU, dp, C, None, None, None, C, 1, ops.ACT_NONE, dprec, mask_in=mask)
         d = L.WgradDesc(P(x), None, C, 0, P(gy), P(y), ops.ACT_LRELU, C, P(dw), P(db), None, P(part), P(cws), B, H, W, 1, 0, 0, 0, 0,
                         None, None, P(mask))
-        if dprec:
+        if dprec == ops.ALGO_WINO:
+            L.check(lib.scm_conv3x3_wgrad_wino(ctypes.byref(d), S()), 'wgrad_wino')
+        elif dprec:
             L.check(lib.scm_conv3x3_wgrad_h16(ctypes.byref(d), dprec, S()), 'wgrad_h16')
         else:
             L.check(lib.scm_conv3x3_wgrad(ctypes.byref(d), S()), 'wgrad')
     torch.cuda.synchronize()
 # the fused decoder + BCE launches of one unrolled step (fp32): forward, backward, at the bench batch
 ops.set_compute_precision('fp32')
+ops.set_conv_algo('winograd')
 from scm_gan_amd import models as M
 dec = M.Decoder(16, 3)
 z = (torch.rand(B, 16, H, W, device='cuda') < 0.5).float().requires_grad_(True)
