@@ -57,6 +57,9 @@ parser.add_argument('--seed', type=int, default=0, help='Seed of weights, data a
 parser.add_argument('--precision', choices=('fp32', 'fp32x3', 'fp16'), default='fp32',
                     help="MFMA operand precision of the 3x3 convs: fp32 = the reference's arithmetic; fp16 = fp16 forward / "
                          "bf16 gradient operands with fp32 accumulation (not in the reference)")
+parser.add_argument('--conv-algo', choices=('winograd', 'direct'), default=None,
+                    help="fp32 algorithm of the wide 3x3 convs (both fp32 operands / fp32 accumulation): winograd = F(2x2,3x3), "
+                         "4/9 of the MFMA products (default); direct = implicit GEMM")
 parser.add_argument('--prefetch', type=int, default=0,
                     help='Depth of the device-side batch queue (datasource.DeviceBatchQueue: worker thread, pinned '
                          'double-buffered uploads, on-device one-hot); 0 = the reference\'s serial loop')
@@ -558,6 +561,8 @@ def main(argv=None):
     # one process per GPU: bind cuda:LOCAL_RANK and join the process group BEFORE any other GPU call
     rank, local_rank, world = dp.init_from_env()
     ops.set_compute_precision(args.precision)
+    if args.conv_algo:
+        ops.set_conv_algo(args.conv_algo)
     torch.manual_seed(args.seed)                   # identical initial replicas on every rank
     latent_dim = 16
     rank_seed = args.seed + dp.SEED_STRIDE * rank  # per-rank data stream and latent-noise stream
