@@ -97,6 +97,13 @@ typedef struct scm_conv3x3_desc {
      * skips of models.py:78,82 feeding conv2/conv6 and conv3/conv5) gets the second consumer's input gradient added
      * in the epilogue of that consumer's gradient convolution instead of by a separate elementwise add. */
     int32_t accumulate_y1;
+    /* scm_conv3x3_wino only (the other entry points refuse them): the 1-bit leaky-relu gate of the activation whose
+     * gradient y1 (y2) is -- words [B][ceil(co1/32)][H*W] ([B][ceil((cout-co1)/32)][H*W]), the gate_mask_out of the layer
+     * that PRODUCED that activation.  When given, every value written (or added) to y1 / y2 is multiplied by the
+     * leaky-relu slope of its own element (1 or 0.01): an input-gradient convolution then hands the layer below a
+     * gradient that is already gated, and that layer's own gradient kernels run with gate_act = 0 -- the gate is
+     * applied once, by the producer's epilogue, instead of twice, by the staging code of both consumers. */
+    const uint32_t* gate_mask_y1; const uint32_t* gate_mask_y2;
 } scm_conv3x3_desc;
 
 int scm_conv3x3(const scm_conv3x3_desc* d, void* stream);

@@ -31,6 +31,7 @@ class ConvDesc(ctypes.Structure):
         ("pad_mode", ctypes.c_int32), ("act", ctypes.c_int32),
         ("gate_mask_out", ctypes.c_void_p), ("gate_mask_in", ctypes.c_void_p),
         ("accumulate_y1", ctypes.c_int32),
+        ("gate_mask_y1", ctypes.c_void_p), ("gate_mask_y2", ctypes.c_void_p),
     ]
 
 

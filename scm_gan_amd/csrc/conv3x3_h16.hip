@@ -603,6 +603,8 @@ extern "C" int scm_conv3x3_h16(const scm_conv3x3_desc* d, int precision, void* s
     k.scale = d->scale; k.bias = d->bias; k.sbias = d->sbias;
     k.y1 = d->y1; k.y2 = d->y2; k.co1 = d->co1;
     k.acc_y1 = d->accumulate_y1;
+    k.ymask1 = k.ymask2 = nullptr;
+    SCM_REQUIRE(!d->gate_mask_y1 && !d->gate_mask_y2, "scm_conv3x3_h16: output gates (gate_mask_y1 / _y2) are applied by scm_conv3x3_wino only");
     k.B = d->B; k.H = d->H; k.W = d->W; k.pad_mode = d->pad_mode; k.act = d->act;
     k.tiles_per_img = 0; k.plane = 0;
     k.mask_in = d->gate_mask_in;

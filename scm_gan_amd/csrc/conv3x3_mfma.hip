@@ -557,6 +557,8 @@ extern "C" int scm_conv3x3(const scm_conv3x3_desc* d, void* stream) {
     k.tiles_per_img = 0; k.plane = 0;
     k.mask_in = d->gate_mask_in;
     k.acc_y1 = d->accumulate_y1;
+    k.ymask1 = k.ymask2 = nullptr;
+    SCM_REQUIRE(!d->gate_mask_y1 && !d->gate_mask_y2, "scm_conv3x3: output gates (gate_mask_y1 / _y2) are applied by scm_conv3x3_wino only");
     k.mask_out = (d->act == SCM_ACT_LRELU && d->cout > 32) ? d->gate_mask_out : nullptr;
     SCM_REQUIRE(!d->gate_mask_out || k.mask_out, "scm_conv3x3: gate_mask_out needs act == LRELU and cout > 32");
     if (d->cout <= 16) return scm_launch_conv3x3_m16(k, (hipStream_t)stream);

@@ -423,8 +423,18 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_kernel(const ConvKArgs a)
                           : (gwp)(a.y2) + ((size_t)b * co2n + (co_w - a.co1)) * plane_b;
         const unsigned loff = (unsigned)(4 * lh) * (unsigned)plane_b + (unsigned)p00 * 4u;
         const unsigned wrow = (unsigned)W * 4u;
-        auto body = [&](auto add_) {
-            constexpr bool ADD = decltype(add_)::value;
+        // leaky-relu gate of the destination activation (gate_mask_y1 / _y2): this wave's 32 channels are one word per
+        // pixel; shifted so that bit (r & 3) + 8 * (r >> 2) is this lane's row r
+        const unsigned* gm = first ? a.ymask1 : a.ymask2;
+        unsigned gw[4] = {0u, 0u, 0u, 0u};
+        if (gm) {
+            const int gnw = ((first ? a.co1 : co2n) + 31) >> 5;
+            const unsigned* gp = gm + ((size_t)b * gnw + ((co_w - (first ? 0 : a.co1)) >> 5)) * HW + p00;
+            const u32x2w g0 = *reinterpret_cast<const u32x2w*>(gp), g1 = *reinterpret_cast<const u32x2w*>(gp + W);
+            gw[0] = g0[0] >> (4 * lh); gw[1] = g0[1] >> (4 * lh); gw[2] = g1[0] >> (4 * lh); gw[3] = g1[1] >> (4 * lh);
+        }
+        auto body = [&](auto add_, auto gate_) {
+            constexpr bool ADD = decltype(add_)::value, YG = decltype(gate_)::value;
             float old[ADD ? 16 : 1][4];
             if constexpr (ADD) {
 #pragma unroll
@@ -459,6 +469,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_kernel(const ConvKArgs a)
                     const float u = fmaf(o[q], sc, badd);
                     o[q] = fmaxf(u, slope * u);          // none (slope 1) / leaky_relu (0.01): bitwise scm_act_sel
                     bits[q] |= (o[q] > 0.f ? 1u : 0u) << (rowu + 4 * lh);
+                    if constexpr (YG) o[q] = (gw[q] & (1u << rowu)) ? o[q] : 0.01f * o[q];
                     if constexpr (ADD) o[q] += old[r][q];
                 }
                 gwp rb = ybase + (size_t)rowu * plane_b;
@@ -479,8 +490,9 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_kernel(const ConvKArgs a)
                 }
             }
         };
-        if (a.acc_y1 && first) body(std::true_type{});
-        else body(std::false_type{});
+        const bool addp = a.acc_y1 && first;
+        if (gm) { if (addp) body(std::true_type{}, std::true_type{}); else body(std::false_type{}, std::true_type{}); }
+        else { if (addp) body(std::true_type{}, std::false_type{}); else body(std::false_type{}, std::false_type{}); }
     } else {
     unsigned bits[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
@@ -510,6 +522,18 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_kernel(const ConvKArgs a)
         }
         if (co < a.cout && tvalid && WINO_ABL != 5) {
             const bool first = co < a.co1;
+            if (const unsigned* gmg = first ? a.ymask1 : a.ymask2) {      // output gate of the destination activation
+                const int cd = first ? co : co - a.co1;
+                const int gnw = ((first ? a.co1 : co2n) + 31) >> 5;
+                const unsigned* gp = gmg + ((size_t)b * gnw + (cd >> 5)) * HW + p00;
+                const unsigned bit = 1u << (cd & 31);
+                o[0] = (gp[0] & bit) ? o[0] : 0.01f * o[0];
+                if (col1) o[1] = (gp[1] & bit) ? o[1] : 0.01f * o[1];
+                if (row1) {
+                    o[2] = (gp[W] & bit) ? o[2] : 0.01f * o[2];
+                    if (col1) o[3] = (gp[W + 1] & bit) ? o[3] : 0.01f * o[3];
+                }
+            }
             float* dst = (first ? a.y1 + ((size_t)b * a.co1 + co) * HW
                                 : a.y2 + ((size_t)b * co2n + (co - a.co1)) * HW) + p00;
             const bool add = a.acc_y1 && first;
@@ -688,6 +712,9 @@ extern "C" int scm_conv3x3_wino(const scm_conv3x3_desc* d, void* stream) {
     k.B = d->B; k.H = d->H; k.W = d->W; k.pad_mode = d->pad_mode; k.act = d->act;
     k.mask_in = d->gate_mask_in;
     k.acc_y1 = d->accumulate_y1;
+    k.ymask1 = d->gate_mask_y1; k.ymask2 = d->gate_mask_y2;
+    SCM_REQUIRE((!d->gate_mask_y1 || (d->co1 & 31) == 0 || d->co1 == d->cout) && ((reinterpret_cast<size_t>(d->gate_mask_y1) | reinterpret_cast<size_t>(d->gate_mask_y2)) & 7) == 0,
+                "scm_conv3x3_wino: output gates need co1 %% 32 == 0 and 8-byte aligned masks");
     k.mask_out = (d->act == SCM_ACT_LRELU && d->cout > 32) ? d->gate_mask_out : nullptr;
     SCM_REQUIRE(!d->gate_mask_out || k.mask_out, "scm_conv3x3_wino: gate_mask_out needs act == LRELU and cout > 32");
     SCM_REQUIRE(d->c2 == 0 || (d->c1 & 7) == 0, "scm_conv3x3_wino: c1 must be a multiple of 8 when x2 is given (c1=%d)", d->c1);

@@ -54,11 +54,15 @@ class Conv2d(nn.Module):
             self._pack_key = key
         return self._packs
 
-    def forward(self, x, x2=None, act_vec=None, act=ops.ACT_NONE, _sn=None, dx1_cell=None, dx2_cell=None):
+    def forward(self, x, x2=None, act_vec=None, act=ops.ACT_NONE, _sn=None, dx1_cell=None, dx2_cell=None,
+                in_masks=None, pregated=False, mask_holder=None):
         """x (and optionally x2, concatenated along channels without being
         materialised); act_vec: (B, A) values of A trailing constant input planes
         (circular 3x3 only).  _sn = (weight_bar, u, v, inv_sigma) from SpectralNorm.
-        dx1_cell / dx2_cell: shared-gradient cells of x / x2 (ops.SharedGradFork)."""
+        dx1_cell / dx2_cell: shared-gradient cells of x / x2 (ops.SharedGradFork).
+        Producer-side gating (ops.pregate_ok): in_masks = the 1-bit leaky-relu gates of x / x2 (this layer's input
+        gradient comes out multiplied by them), pregated = every consumer of this layer's output does the same for
+        it, mask_holder = a dict that receives this layer's own gate under 'mask'."""
         if _sn is not None:
             w, u, v, inv_sigma = _sn
         else:
@@ -68,7 +72,8 @@ class Conv2d(nn.Module):
             if act_vec is not None and self.padding_mode != "circular":
                 raise ValueError("constant action planes fold into a bias only under circular padding")
             cfg = {"pad": ops.PAD_CIRCULAR if self.padding_mode == "circular" else ops.PAD_ZERO, "act": act,
-                   "transposed": False, "packs": self._get_packs(w, cin_conv), "dx1_cell": dx1_cell, "dx2_cell": dx2_cell}
+                   "transposed": False, "packs": self._get_packs(w, cin_conv), "dx1_cell": dx1_cell, "dx2_cell": dx2_cell,
+                   "in_masks": in_masks, "pregated": pregated, "mask_holder": mask_holder}
             return ops.Conv3x3Fn.apply(x, x2, act_vec, w, self.bias, inv_sigma, u, v, cfg)
         if x2 is not None or act_vec is not None:
             raise ValueError("two-input / action-plane forms need the 3x3 same-size geometry")

@@ -63,19 +63,28 @@ class Transition(nn.Module):
         batch_size_actions, num_actions = a.shape
         assert batch_size == batch_size_actions
         L = ops.ACT_LRELU
+        # Producer-side gating (ops.pregate_ok): every consumer of the five leaky-relu maps is one of the convolutions
+        # below, so each layer's input-gradient kernel gates the gradient it hands down and the layers run their own
+        # gradient kernels ungated.  Not when the caller gets the maps themselves (return_all): a gradient arriving
+        # from outside would not be gated.
+        pg = (torch.is_grad_enabled() and not return_all and ops.pregate_ok(height, width)
+              and os.environ.get("SCM_NO_SHARED_GRAD", "0") in ("", "0"))
+        m1, m2, m3, m4, m5 = ({} if pg else None for _ in range(5))
+        mk = (lambda h: h["mask"]) if pg else (lambda h: None)
         # the action planes (models.py:68-73) enter conv1 as a per-sample bias
-        skip1 = self.conv1(s, None, a, act=L)
+        skip1 = self.conv1(s, None, a, act=L, pregated=pg, mask_holder=m1)
         if torch.is_grad_enabled() and skip1.requires_grad and os.environ.get("SCM_NO_SHARED_GRAD", "0") in ("", "0"):
             # the two U-net skips have two consumers each (models.py:78-101): their gradients meet in one buffer
             # inside the gradient convolutions (ops.SharedGradFork) instead of in an elementwise add
             c1, c2 = {}, {}
             s1a, s1b = ops.SharedGradFork.apply(skip1, c1)
-            skip2 = self.conv2(s1a, act=L, dx1_cell=c1)
+            skip2 = self.conv2(s1a, act=L, dx1_cell=c1, in_masks=(mk(m1), None), pregated=pg, mask_holder=m2)
             s2a, s2b = ops.SharedGradFork.apply(skip2, c2)
-            out3 = self.conv3(s2a, act=L, dx1_cell=c2)
-            out4 = self.conv4(out3, act=L)
-            out5 = self.conv5(out4, s2b, act=L, dx2_cell=c2)      # cat([x, skip2]) never materialised
-            p = self.conv6(out5, s1b, act=ops.ACT_SIGMOID, dx2_cell=c1)   # cat([x, skip1])
+            out3 = self.conv3(s2a, act=L, dx1_cell=c2, in_masks=(mk(m2), None), pregated=pg, mask_holder=m3)
+            out4 = self.conv4(out3, act=L, in_masks=(mk(m3), None), pregated=pg, mask_holder=m4)
+            out5 = self.conv5(out4, s2b, act=L, dx2_cell=c2, in_masks=(mk(m4), mk(m2)), pregated=pg,
+                              mask_holder=m5)                                          # cat([x, skip2]) never materialised
+            p = self.conv6(out5, s1b, act=ops.ACT_SIGMOID, dx2_cell=c1, in_masks=(mk(m5), mk(m1)))   # cat([x, skip1])
         else:
             skip2 = self.conv2(skip1, act=L)
             out3 = self.conv3(skip2, act=L)
@@ -112,10 +121,13 @@ class Encoder(nn.Module):
     def forward(self, x):
         batch_size, frames, channels, height, width = x.shape
         x = x.reshape(batch_size, frames * channels, height, width)
-        x = self.conv1(x, act=ops.ACT_LRELU)
-        x = self.conv2(x, act=ops.ACT_LRELU)
-        x = self.conv3(x, act=ops.ACT_LRELU)
-        return self.conv4(x, act=ops.ACT_SIGMOID)
+        pg = torch.is_grad_enabled() and ops.pregate_ok(height, width)       # producer-side gating, as in Transition
+        m1, m2, m3 = ({} if pg else None for _ in range(3))
+        mk = (lambda h: h["mask"]) if pg else (lambda h: None)
+        x = self.conv1(x, act=ops.ACT_LRELU, pregated=pg, mask_holder=m1)
+        x = self.conv2(x, act=ops.ACT_LRELU, in_masks=(mk(m1), None), pregated=pg, mask_holder=m2)
+        x = self.conv3(x, act=ops.ACT_LRELU, in_masks=(mk(m2), None), pregated=pg, mask_holder=m3)
+        return self.conv4(x, act=ops.ACT_SIGMOID, in_masks=(mk(m3), None))
 
 
 class Discriminator(nn.Module):

@@ -235,8 +235,10 @@ use_gate_mask = os.environ.get("SCM_NO_GATE_MASK", "0") in ("", "0")
 
 
 def _conv3x3_raw(x1, x2, gate1, gate2, gate_act, wpack, cout, scale, bias, sbias, co1, pad, act, prec=0,
-                 mask_out=None, mask_in=None, y1_acc=None):
-    """y1_acc: an existing (B, co1, H, W) tensor the first co1 output channels are ADDED to (accumulate_y1)."""
+                 mask_out=None, mask_in=None, y1_acc=None, ymask1=None, ymask2=None):
+    """y1_acc: an existing (B, co1, H, W) tensor the first co1 output channels are ADDED to (accumulate_y1).
+    ymask1 / ymask2: leaky-relu gate masks of the activations whose gradients y1 / y2 are (gate_mask_y1 / _y2:
+    the Winograd kernel multiplies what it writes by the slope of its own element)."""
     lib = L.lib()
     B, c1, H, W = x1.shape
     c2 = 0 if x2 is None else x2.shape[1]
@@ -244,7 +246,7 @@ def _conv3x3_raw(x1, x2, gate1, gate2, gate_act, wpack, cout, scale, bias, sbias
     y2 = _new(x1, B, cout - co1, H, W) if co1 < cout else None
     d = L.ConvDesc(_p(x1), _p(x2), c1, c2, _p(gate1), _p(gate2), gate_act, _p(wpack), cout, _p(scale), _p(bias),
                    _p(sbias), _p(y1), _p(y2), co1, B, H, W, pad, act, _p(mask_out), _p(mask_in),
-                   0 if y1_acc is None else 1)
+                   0 if y1_acc is None else 1, _p(ymask1), _p(ymask2))
     if kernel_timer is not None:
         ev = kernel_timer.bracket(conv_kernel_name(cout, prec), 2.0 * B * H * W * cout * (c1 + c2) * 9)
         ev[0].record()
@@ -333,6 +335,21 @@ def _grad_sink(param):
     return g
 
 
+# Producer-side gating of gradients: inside Encoder / Transition every consumer of a leaky-relu
+# activation is a wide convolution whose input-gradient kernel (Winograd) can multiply what it writes by the slope of
+# the element it writes to -- the layer that produced the activation then receives a gradient that is already gated
+# and runs its own gradient kernels without a gate.  The models decide per call (pregate_ok); SCM_NO_PREGATE=1 keeps
+# the consumer-side gate everywhere.
+use_pregate = os.environ.get("SCM_NO_PREGATE", "0") in ("", "0")
+
+
+def pregate_ok(H, W):
+    """Whether the gradients of a leaky-relu activation map of this frame size can be gated by their producers: the
+    default fp32 Winograd kernels must serve every input-gradient convolution of the chain."""
+    return (use_pregate and use_gate_mask and _conv_algo[0] == "winograd" and _precision[0] == "fp32"
+            and WINO_MIN_CIN <= 16 and WINO_MIN_COUT <= 64 and wino_serves(H, W))
+
+
 # -------------------------------------------------------------- conv 3x3
 class Conv3x3Fn(Function):
     """y = act(conv3x3(cat(x1, x2), W_eff) + bias [+ action-plane bias]),
@@ -379,6 +396,8 @@ class Conv3x3Fn(Function):
             mask = torch.empty((B, (cout + 31) // 32, H, W), device=x1.device, dtype=torch.int32)
         y, _ = _conv3x3_raw(x1, x2, None, None, 0, fpack, cout, inv_sigma, bias, sbias, cout, cfg["pad"], cfg["act"],
                             fprec, mask_out=mask)
+        if cfg.get("mask_holder") is not None:
+            cfg["mask_holder"]["mask"] = mask          # for the consumers of y (producer-side gating)
         ctx.cfg = cfg
         ctx.dprec = dprec
         ctx.mask = mask
@@ -396,6 +415,12 @@ class Conv3x3Fn(Function):
         B, c1, c2, H, W, cout, cin_total = ctx.shape
         gy = _chk(gy, "conv3x3.backward")
         act = cfg["act"]
+        gmask = ctx.mask
+        if cfg.get("pregated"):
+            # every producer of gy multiplied it by this layer's leaky-relu slopes already (gate_mask_y1 / _y2)
+            assert act == ACT_LRELU and ctx.mask is not None
+            act, gmask = ACT_NONE, None
+        in_masks = cfg.get("in_masks") or (None, None)
         need_x1, need_x2, need_a, need_w, need_b = ctx.needs_input_grad[:5]
         dx1 = dx2 = d_act = dw = db = None
         if need_x1 or need_x2:
@@ -406,8 +431,12 @@ class Conv3x3Fn(Function):
             dprec = ctx.dprec
             if dprec == ALGO_WINO and (gy.data_ptr() | y.data_ptr()) % 8:
                 dpack, dprec = cfg["packs"][5], PREC_F32          # (an oddly offset gradient view: direct kernel)
+            if (in_masks[0] is not None or in_masks[1] is not None) and dprec != ALGO_WINO:
+                raise RuntimeError("scm_gan_amd.conv3x3.backward: producer-side gating needs the Winograd input-gradient "
+                                   "kernel (ops.pregate_ok)")
             dx1, dx2 = _conv3x3_raw(gy, None, y if act else None, None, act, dpack, c1 + c2, inv_sigma, None, None, c1,
-                                    cfg["pad"], ACT_NONE, dprec, mask_in=ctx.mask, y1_acc=acc1)
+                                    cfg["pad"], ACT_NONE, dprec, mask_in=gmask, y1_acc=acc1, ymask1=in_masks[0],
+                                    ymask2=in_masks[1])
             if cell1 is not None:
                 cell1["buf"] = dx1
             if cell2 is not None and dx2 is not None:
@@ -437,7 +466,7 @@ class Conv3x3Fn(Function):
                 dot_part = _new(gy, (9 * cout * (c1 + c2) + 255) // 256)
             d = L.WgradDesc(_p(x1), _p(x2), c1, c2, _p(gy), _p(y) if act else None, act, cout, _p(dw_eff), _p(db),
                             _p(csum), _p(part), _p(cws), B, H, W, cfg["pad"], int(cfg["transposed"]), acc_flag,
-                            cin_total, 0, _p(w) if dot_part is not None else None, _p(dot_part), _p(ctx.mask))
+                            cin_total, 0, _p(w) if dot_part is not None else None, _p(dot_part), _p(gmask))
             wprec = ctx.dprec if ctx.dprec in (PREC_F16, PREC_BF16) else PREC_F32
             if compute_precision() == "fp32x3":
                 # the split kernel takes 128-wide weight gradients of layers with more than 16 input channels (at any batch:

@@ -198,3 +198,74 @@ def test_bitwise_reproducible_and_layer_fallback():
         assert all(torch.equal(p, q) for p, q in zip(a[3:], d[3:]))
     finally:
         ops.set_conv_algo(prev)
+
+
+def test_output_gate_of_the_input_gradient_kernel(K):
+    """gate_mask_y1 / _y2: what the Winograd kernel writes (or adds) to y1 / y2 is multiplied by the leaky-relu slope of
+    the element it writes to -- bitwise the ungated result times 1 or 0.01, for split outputs, with accumulate, on
+    the fast and the generic epilogue (ragged channels, odd height)."""
+    from scm_gan_amd import _lib as L
+    torch.manual_seed(4)
+    for (B, cin, c1, c2, H, W, acc) in [(2, 128, 128, 128, 16, 16, True), (1, 16, 128, 128, 64, 64, False),
+                                        (2, 64, 128, 0, 16, 16, False), (2, 64, 96, 64, 9, 8, True)]:
+        cout = c1 + c2
+        dy = torch.randn(B, cin, H, W, device="cuda")
+        w = torch.randn(cin, cout, 3, 3, device="cuda") * 0.05          # the layer's weight: cout inputs -> cin outputs
+        _, dp = K.pack(w, 1)
+        a1 = torch.randn(B, c1, H, W, device="cuda")                     # activations whose gradients y1 / y2 are
+        a2 = torch.randn(B, c2, H, W, device="cuda") if c2 else None
+        m1, m2 = mask_words(a1), (mask_words(a2) if c2 else None)
+
+        def run(masks):
+            base = torch.randn(B, c1, H, W, device="cuda", generator=torch.Generator("cuda").manual_seed(1)) if acc else None
+            y1 = base.clone() if acc else torch.empty(B, c1, H, W, device="cuda")
+            y2 = torch.empty(B, c2, H, W, device="cuda") if c2 else None
+            d = L.ConvDesc(K.P(dy), None, cin, 0, None, None, 0, K.P(dp), cout, None, None, None, K.P(y1), K.P(y2), c1, B, H, W,
+                           1, 0, None, None, 1 if acc else 0, K.P(m1) if masks else None, K.P(m2) if (masks and c2) else None)
+            L.check(K.lib.scm_conv3x3_wino(ctypes.byref(d), K.S()), "conv")
+            return (y1 - base if acc else y1), y2, base
+        g1, g2, _ = run(True)
+        u1, u2, _ = run(False)
+        s1 = torch.where(a1 > 0, torch.ones_like(a1), torch.full_like(a1, 0.01))
+        if acc:         # (y1 = base + gated: compare after removing base, to fp32 rounding of the add)
+            assert float((g1 - u1 * s1).abs().max()) < 1e-6 * max(1.0, float(u1.abs().max()))
+        else:
+            assert torch.equal(g1, u1 * s1)
+        if c2:
+            s2 = torch.where(a2 > 0, torch.ones_like(a2), torch.full_like(a2, 0.01))
+            assert torch.equal(g2, u2 * s2)
+    # the direct entry point refuses output gates instead of ignoring them
+    d = L.ConvDesc(K.P(dy), None, cin, 0, None, None, 0, K.P(dp), cout, None, None, None, K.P(a1), K.P(a2), c1, B, H, W, 1, 0,
+                   None, None, 0, K.P(m1), None)
+    assert K.lib.scm_conv3x3(ctypes.byref(d), K.S()) != 0
+
+
+def test_producer_side_gating_equals_consumer_side():
+    """Encoder + Transition backward with the gate applied by the producers of each gradient (default) against the same
+    pass with every layer gating its own incoming gradient (ops.use_pregate = False): same gradients to fp32 rounding
+    (a two-consumer sum is gated per contribution instead of once)."""
+    import weights as WS
+    from scm_gan_amd import models as M, ops
+    torch.manual_seed(0)
+    res = {}
+    for pre in (True, False):
+        ops.use_pregate = pre
+        try:
+            enc, tr = M.Encoder(16, 3), M.Transition(16, 5)
+            enc.load_state_dict(WS.to_torch(WS.encoder_state(30)))
+            tr.load_state_dict(WS.to_torch(WS.transition_state(31)))
+            enc.train(); tr.train()
+            g = torch.Generator("cuda").manual_seed(5)
+            x = (torch.rand(2, 3, 3, 32, 32, device="cuda", generator=g) < 0.3).float()
+            a = torch.eye(5, device="cuda")[[1, 3]]
+            tr.set_noise([torch.rand(2, 16, 32, 32, device="cuda", generator=g)])
+            z = enc(x)
+            assert ops.pregate_ok(32, 32) == pre
+            z2 = tr(z, a)
+            (z2 * torch.rand(z2.shape, device="cuda", generator=g)).sum().backward()
+            res[pre] = [p.grad.clone() for m in (enc, tr) for p in m.parameters() if p.grad is not None]
+        finally:
+            ops.use_pregate = True
+    assert len(res[True]) == len(res[False]) >= 20
+    for p, q in zip(res[True], res[False]):
+        assert float((p - q).abs().max()) <= 2e-6 * max(1e-6, float(q.abs().max())), float((p - q).abs().max())
