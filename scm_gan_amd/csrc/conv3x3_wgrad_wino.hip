@@ -114,14 +114,25 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wgrad_wino_kernel(const WgradK
 #define IC(n) std::integral_constant<int, (n)>{}
 #define SB() __builtin_amdgcn_sched_barrier(0)
 
-    // chunk k of the band: patch row ty = tr0 + k / nchr, patches 8*cx .. 8*cx+7, cx = k % nchr.  The loads of a chunk
-    // past the end re-read the last chunk (never used).  ld_setup fixes the chunk's lane offsets, ld_xrow / ld_xedge /
-    // ld_drow request one row each into register set P.
+    // Chunk k of the band walks DOWN a column of patches: cx = k / ntr (patches 8*cx .. 8*cx+7), patch row ty = tr0 +
+    // k % ntr.  Consecutive chunks then share two of their four input rows (rows 2, 3 of chunk k are rows 0, 1 of chunk
+    // k+1): those are copied from the other register set instead of being requested again (row_reuse), except at the
+    // top of a column.  The loads of a chunk past the end re-read the last chunk (never used).  ld_setup fixes the
+    // chunk's lane offsets, ld_xrow / ld_xedge / ld_drow request one row each into register set P.
+    const int ntr = tr1 > tr0 ? tr1 - tr0 : 1;
+    auto chunk_pos = [&](int k, int& ty, int& cx) {
+        const int kc = k < nchunk ? k : (nchunk > 0 ? nchunk - 1 : 0);
+        cx = kc / ntr;
+        ty = tr0 + (kc - cx * ntr);
+    };
+    bool l_reuse[2] = {false, false};       // rows 0, 1 of the set came from the previous chunk (already fixed)
     auto ld_setup = [&](int k, auto p_) {
         constexpr int P = decltype(p_)::value;
-        const int kc = k < nchunk ? k : (nchunk > 0 ? nchunk - 1 : 0);
-        l_ty[P] = tr0 + kc / nchr;
-        const int cx = kc - (kc / nchr) * nchr;
+        int ty, cx;
+        chunk_pos(k, ty, cx);
+        l_ty[P] = ty;
+        // (k >= 1: the chunk before it is in the other set; past the end the clamped chunk repeats: no reuse)
+        l_reuse[P] = k >= 1 && k < nchunk && ty > tr0;
         const int ix0 = 16 * cx + 4 * q;                 // first image column of the pair's outputs
         const int ixm = ix0 < W ? ix0 : W - 4;           // (a pair past the row end reads the last one: finite data)
         // Of the pair's six columns the middle four are one aligned 16-byte load; the outer two are the neighbouring
@@ -199,13 +210,27 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wgrad_wino_kernel(const WgradK
             mr[P][I][0] = m[0]; mr[P][I][1] = m[1]; mr[P][I][2] = m[2]; mr[P][I][3] = m[3];
         }
     };
-    auto load_chunk = [&](int k, auto p_) {
+    auto load_chunk = [&](int k, auto p_) {          // (prologue: all four rows, no reuse)
+        constexpr int P = decltype(p_)::value;
         ld_setup(k, p_);
+        l_reuse[P] = false;
         ld_xrow(p_, IC(0)); ld_xrow(p_, IC(1)); ld_xrow(p_, IC(2)); ld_xrow(p_, IC(3));
         ld_xedge(p_, IC(0)); ld_xedge(p_, IC(1)); ld_xedge(p_, IC(2)); ld_xedge(p_, IC(3));
         ld_drow(p_, IC(0)); ld_drow(p_, IC(1));
     };
-    auto fix_chunk = [&](auto p_) { ld_xfix(p_, IC(0)); ld_xfix(p_, IC(1)); ld_xfix(p_, IC(2)); ld_xfix(p_, IC(3)); };
+    auto fix_chunk = [&](auto p_) {
+        constexpr int P = decltype(p_)::value;
+        if (!l_reuse[P]) { ld_xfix(p_, IC(0)); ld_xfix(p_, IC(1)); }
+        ld_xfix(p_, IC(2)); ld_xfix(p_, IC(3));
+    };
+    // rows 2, 3 of the (fixed, not yet transformed) set Q are rows 0, 1 of the next chunk in set P
+    auto row_reuse = [&](auto p_, auto q_) {
+        constexpr int P = decltype(p_)::value, Q = decltype(q_)::value;
+        if (l_reuse[P]) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) { xr[P][0][j] = xr[Q][2][j]; xr[P][1][j] = xr[Q][3][j]; }
+        }
+    };
     // gate, validity and channel sum of the loaded output gradient (chunk k, register set P)
     auto gate_chunk = [&](int k, auto p_) {
         constexpr int P = decltype(p_)::value;
@@ -221,7 +246,8 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wgrad_wino_kernel(const WgradK
                 if constexpr (GATED == 1) v *= scm_act_grad_from_out(gr[P][i][j], a.gate_act);
                 if constexpr (GATED == 2) v = (mr[P][i][j] & mbit) ? v : 0.01f * v;
                 if constexpr (EDGE) {
-                    const int ty = tr0 + kc / nchr, cx = kc - (kc / nchr) * nchr;
+                    int ty, cx;
+                    chunk_pos(kc, ty, cx);
                     const bool ok = (2 * ty + i < H) && (16 * cx + 4 * q + j < W);
                     v = ok ? v * chv : 0.f;
                 }
@@ -284,15 +310,14 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wgrad_wino_kernel(const WgradK
         constexpr auto PN = IC(P ^ 1);
         mf(IC(0));
         if constexpr (F < 15 && DO_R) ab_read(p_, IC(F < 15 ? F + 1 : 0));
-        if constexpr (F == 0 && DO_L) { ld_setup(k + 2, p_); ld_xrow(p_, IC(0)); }
-        if constexpr (F == 1 && DO_L) ld_xrow(p_, IC(2));
-        if constexpr (F == 2 && DO_L) ld_xedge(p_, IC(0));
-        if constexpr (F == 3 && DO_L) ld_xedge(p_, IC(2));
-        if constexpr (F == 4 && DO_L) ld_drow(p_, IC(0));
+        if constexpr (F == 0 && DO_L) { ld_setup(k + 2, p_); ld_xrow(p_, IC(2)); }
+        if constexpr (F == 1 && DO_L) ld_xedge(p_, IC(2));
+        if constexpr (F == 2 && DO_L) ld_drow(p_, IC(0));
+        if constexpr (F == 3 && DO_L) { if (!l_reuse[P]) { ld_xrow(p_, IC(0)); ld_xedge(p_, IC(0)); } }
         SB();
         mf(IC(1));
         if constexpr (F == 0 && DO_T) gate_chunk(k + 1, PN);
-        if constexpr (F == 1 && DO_T) { dy_xform(PN, IC(0)); dy_xform(PN, IC(1)); fix_chunk(PN); }
+        if constexpr (F == 1 && DO_T) { dy_xform(PN, IC(0)); dy_xform(PN, IC(1)); fix_chunk(PN); if constexpr (DO_L) row_reuse(p_, PN); }
         if constexpr (F == 2 && DO_T) { x_vert(PN, IC(0)); x_vert(PN, IC(1)); x_vert(PN, IC(2)); }
         if constexpr (F == 3 && DO_T) { x_vert(PN, IC(3)); x_vert(PN, IC(4)); x_vert(PN, IC(5)); }
         if constexpr (F == 4 && DO_T) { x_horz(PN, IC(0), IC(0)); x_horz(PN, IC(0), IC(1)); }
@@ -305,11 +330,10 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wgrad_wino_kernel(const WgradK
         if constexpr (F >= 8 && DO_W) { dy_write(PN, IC(F >= 8 ? 2 * (F - 8) + 1 : 0)); x_write(PN, IC(F >= 8 ? 2 * (F - 8) + 1 : 0)); }
         SB();
         mf(IC(3));
-        if constexpr (F == 0 && DO_L) ld_xrow(p_, IC(1));
-        if constexpr (F == 1 && DO_L) ld_xrow(p_, IC(3));
-        if constexpr (F == 2 && DO_L) ld_xedge(p_, IC(1));
-        if constexpr (F == 3 && DO_L) ld_xedge(p_, IC(3));
-        if constexpr (F == 4 && DO_L) ld_drow(p_, IC(1));
+        if constexpr (F == 0 && DO_L) ld_xrow(p_, IC(3));
+        if constexpr (F == 1 && DO_L) ld_xedge(p_, IC(3));
+        if constexpr (F == 2 && DO_L) ld_drow(p_, IC(1));
+        if constexpr (F == 3 && DO_L) { if (!l_reuse[P]) { ld_xrow(p_, IC(1)); ld_xedge(p_, IC(1)); } }
         SB();
     };
     auto chunk_body = [&](int k, auto p_) {

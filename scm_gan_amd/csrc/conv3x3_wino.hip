@@ -345,6 +345,28 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_kernel(const ConvKArgs a)
         SB();
     };
 
+    // this lane's output patch (epilogue), and -- requested now, used after the K loop -- the gate words of the
+    // destination activation for its four pixels (gate_mask_y1 / _y2; meaningful on the fast epilogue path only)
+    const int co2n = a.cout - a.co1;
+    const int t = t0 + wn * 32 + l31;
+    const bool tvalid = t < ntiles;
+    const int tc = tvalid ? t : ntiles - 1;
+    const int ty = tc / TCW, tx = tc - ty * TCW;
+    const int oy = 2 * ty, ox = 2 * tx;
+    const bool row1 = tvalid && oy + 1 < H, col1 = ox + 1 < W;
+    const int p00 = oy * W + ox;
+    unsigned gwl[4] = {0u, 0u, 0u, 0u};
+    {
+        const int cw = cg * WINO_CO + wm * 32;
+        const bool fst = cw < a.co1;
+        const unsigned* gmx = fst ? a.ymask1 : a.ymask2;
+        if (gmx && row1 && cw + 32 <= a.cout) {
+            const int gnw = ((fst ? a.co1 : co2n) + 31) >> 5;
+            const unsigned* gp = gmx + ((size_t)b * gnw + ((cw - (fst ? 0 : a.co1)) >> 5)) * HW + p00;
+            const u32x2w g0 = *reinterpret_cast<const u32x2w*>(gp), g1 = *reinterpret_cast<const u32x2w*>(gp + W);
+            gwl[0] = g0[0]; gwl[1] = g0[1]; gwl[2] = g1[0]; gwl[3] = g1[1];
+        }
+    }
 #ifdef WINO_TIMING
     unsigned long long t_acc[4] = {0, 0, 0, 0};
     unsigned long long t_last = clock64();
@@ -395,14 +417,6 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_kernel(const ConvKArgs a)
     const float sc = a.scale ? *a.scale : 1.f;
     const bool sigmoid = a.act == SCM_ACT_SIGMOID;
     const float slope = scm_act_slope(a.act);
-    const int co2n = a.cout - a.co1;
-    const int t = t0 + wn * 32 + l31;
-    const bool tvalid = t < ntiles;
-    const int tc = tvalid ? t : ntiles - 1;
-    const int ty = tc / TCW, tx = tc - ty * TCW;
-    const int oy = 2 * ty, ox = 2 * tx;
-    const bool row1 = tvalid && oy + 1 < H, col1 = ox + 1 < W;
-    const int p00 = oy * W + ox;
     // 8-byte stores need even row pitch and 8-byte aligned bases (wave-uniform)
     const bool vec = (W & 1) == 0 && ((reinterpret_cast<size_t>(a.y1) | reinterpret_cast<size_t>(a.y2) |
                                         reinterpret_cast<size_t>(a.mask_out)) & 7) == 0;
@@ -426,13 +440,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_kernel(const ConvKArgs a)
         // leaky-relu gate of the destination activation (gate_mask_y1 / _y2): this wave's 32 channels are one word per
         // pixel; shifted so that bit (r & 3) + 8 * (r >> 2) is this lane's row r
         const unsigned* gm = first ? a.ymask1 : a.ymask2;
-        unsigned gw[4] = {0u, 0u, 0u, 0u};
-        if (gm) {
-            const int gnw = ((first ? a.co1 : co2n) + 31) >> 5;
-            const unsigned* gp = gm + ((size_t)b * gnw + ((co_w - (first ? 0 : a.co1)) >> 5)) * HW + p00;
-            const u32x2w g0 = *reinterpret_cast<const u32x2w*>(gp), g1 = *reinterpret_cast<const u32x2w*>(gp + W);
-            gw[0] = g0[0] >> (4 * lh); gw[1] = g0[1] >> (4 * lh); gw[2] = g1[0] >> (4 * lh); gw[3] = g1[1] >> (4 * lh);
-        }
+        unsigned gw[4] = {gwl[0] >> (4 * lh), gwl[1] >> (4 * lh), gwl[2] >> (4 * lh), gwl[3] >> (4 * lh)};
         auto body = [&](auto add_, auto gate_) {
             constexpr bool ADD = decltype(add_)::value, YG = decltype(gate_)::value;
             float old[ADD ? 16 : 1][4];
