@@ -54,19 +54,24 @@ __device__ unsigned long long wino_ticks[4];
 #define WINO_TICK(i)
 #endif
 
-template <int NJ, int GATED, int PADC>
+// CW: output channels per workgroup.  64: 2 x 2 waves = 64 co x 64 patches (any frame).  128: 4 x 1 waves = 128 co x 32
+// patches -- each transformed patch feeds twice the MFMAs and the raw rows are staged once instead of once per 64-co
+// group; for layers with a multiple of 128 output channels on frames whose patch rows divide 32 (W = 16, 32, 64).
+template <int NJ, int GATED, int PADC, int CW>
 __global__ void __launch_bounds__(256, 1) conv3x3_wino_kernel(const ConvKArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int PLANE = NJ * 512;                   // floats per channel of the raw halo rows (NJ pairs per thread)
     float* const RAW = smem;                          // [KC][PLANE]
-    float* const VB = smem + KC * PLANE;              // two stages of V [16][2][64][4]
-    float* const BIASL = VB + 2 * WINO_SLAB;          // [64]
+    constexpr int TW = CW == 64 ? 64 : 32;            // patches per workgroup
+    constexpr int VST = 128 * TW;                     // floats of one V stage [16][2][TW][4]
+    float* const VB = smem + KC * PLANE;              // two stages of V
+    float* const BIASL = VB + 2 * VST;                // [CW]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lh = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wn = CW == 64 ? (wave & 1) : 0;         // patch half of the wave (CW 64); its 32 channels: co_w below
     const int W = a.W, H = a.H, HW = H * W;           // W is even (scm_conv3x3_wino_serves)
     const int TCW = W >> 1, TRH = (H + 1) >> 1;
     const int ntiles = TCW * TRH;
@@ -76,16 +81,20 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_kernel(const ConvKArgs a)
     const int b = blockIdx.x / a.tiles_per_img;
     const int wt = blockIdx.x - b * a.tiles_per_img;
     const int cg = blockIdx.y;
-    const int t0 = wt * WINO_TILES;
+    const int t0 = wt * TW;
     const int ty0 = t0 / TCW;
-    int tlast = t0 + WINO_TILES - 1;
+    int tlast = t0 + TW - 1;
     if (tlast > ntiles - 1) tlast = ntiles - 1;
     const int nrows = 2 * (tlast / TCW - ty0) + 4;
     const int HPR = (W + 4) >> 1;                     // pairs per raw row
     const int npair = nrows * HPR;
 
-    if (tid < WINO_CO) {      // bias table for the epilogue (visible after the main loop's barriers)
-        const int co = cg * WINO_CO + tid;
+    // this wave's 32 output channels: 64-channel group cgw of the filter pack, half wm of it
+    const int cgw = CW == 64 ? cg : 2 * cg + (wave >> 1);
+    const int wm = CW == 64 ? (wave >> 1) : (wave & 1);
+    const int co_w = cgw * 64 + wm * 32, co_l = co_w - cg * CW;
+    if (tid < CW) {           // bias table for the epilogue (visible after the main loop's barriers)
+        const int co = cg * CW + tid;
         const int coc = co < a.cout ? co : a.cout - 1;
         float v = 0.f;
         if (a.bias) v += a.bias[coc];
@@ -128,7 +137,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_kernel(const ConvKArgs a)
     // this thread's transform item: tile (lane) x channel pair (wave) of the chunk
     int traw;               // offset of its 4x4 patch (raw slot 2*tx + 2 = image column 2*tx - 1, even) in a raw plane
     {
-        int t = t0 + lane;
+        int t = t0 + (CW == 64 ? lane : (tid & 31));
         if (t > ntiles - 1) t = ntiles - 1;
         const int ty = t / TCW, tx = t - ty * TCW;
         traw = 2 * (ty - ty0) * ROWPL + 2 * tx + 2;
@@ -158,7 +167,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_kernel(const ConvKArgs a)
     gcp gb2 = (GATED == 1 && a.c2) ? (gcp)(a.gate2) + ((size_t)b * a.c2 - a.c1) * plane_b : gb1;
     gcp mb = GATED == 2 ? (gcp)(a.mask_in) + (size_t)b * mask_nw * plane_b : nullptr;
     // this wave's half (wm) of the co group's transformed filters: per chunk [16 positions][64 lanes] float4
-    gcp ub = (gcp)(a.wpack) + ((size_t)cg * nchunk * 2 + wm) * (WINO_SLAB / 2) * 4;
+    gcp ub = (gcp)(a.wpack) + ((size_t)cgw * nchunk * 2 + wm) * (WINO_SLAB / 2) * 4;
     unsigned uoff[4];       // lane * 16 + k * 4096: position F is read at uoff[F >> 2] + (F & 3) * 1024 (immediate)
 #pragma unroll
     for (int k = 0; k < 4; ++k) uoff[k] = lane * 16 + k * 4096;
@@ -256,14 +265,18 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_kernel(const ConvKArgs a)
     // that are dealt out over the MFMAs:  rd<cc,i>: one patch row from RAW;  col<cc,i>: along x of row i;
     // row<cc,j>: along y of column j -> vv[cc][4*i+j];  vw<f>: the pair of position f -> V[f][half][tile][step]
     // (MFMA k index of local channel c: half = c >> 2, step = c & 3)
+    // (CW 128: 32 patches x 8 channels = one (patch, channel) item per thread: only CC = 0 is used)
+    const int tch = CW == 64 ? 2 * wave : (tid >> 5);         // first local channel of the item
     auto t_rd = [&](auto cc_, auto i_) {
         constexpr int CC = decltype(cc_)::value, I = decltype(i_)::value;
-        const float* rp = RAW + (2 * wave + CC) * PLANE + traw + I * ROWPL;
+        if constexpr (CW == 128 && CC == 1) return;
+        const float* rp = RAW + (tch + CC) * PLANE + traw + I * ROWPL;
         const f32x2 lo = *reinterpret_cast<const f32x2*>(rp), hi = *reinterpret_cast<const f32x2*>(rp + 2);
         dd[CC][I][0] = lo[0]; dd[CC][I][1] = lo[1]; dd[CC][I][2] = hi[0]; dd[CC][I][3] = hi[1];
     };
     auto t_col = [&](auto cc_, auto i_) {
         constexpr int CC = decltype(cc_)::value, I = decltype(i_)::value;
+        if constexpr (CW == 128 && CC == 1) return;
         const float d0 = dd[CC][I][0], d1 = dd[CC][I][1], d2 = dd[CC][I][2], d3 = dd[CC][I][3];
         dd[CC][I][0] = d0 - d2;
         dd[CC][I][1] = d1 + d2;
@@ -272,6 +285,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_kernel(const ConvKArgs a)
     };
     auto t_row = [&](auto cc_, auto j_) {
         constexpr int CC = decltype(cc_)::value, J = decltype(j_)::value;
+        if constexpr (CW == 128 && CC == 1) return;
         const float c0 = dd[CC][0][J], c1 = dd[CC][1][J], c2 = dd[CC][2][J], c3 = dd[CC][3][J];
         vv[CC][0 + J] = c0 - c2;
         vv[CC][4 + J] = c1 + c2;
@@ -280,14 +294,18 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_kernel(const ConvKArgs a)
     };
     auto t_vw = [&](int buf, auto f_) {
         constexpr int F = decltype(f_)::value;
-        float* vp = VB + buf * WINO_SLAB + ((wave >> 1) * 64 + lane) * 4 + (wave & 1) * 2 + F * 512;
-        f32x2 o;
-        o[0] = vv[0][F]; o[1] = vv[1][F];
-        *reinterpret_cast<f32x2*>(vp) = o;
+        if constexpr (CW == 64) {
+            float* vp = VB + buf * VST + ((wave >> 1) * 64 + lane) * 4 + (wave & 1) * 2 + F * 512;
+            f32x2 o;
+            o[0] = vv[0][F]; o[1] = vv[1][F];
+            *reinterpret_cast<f32x2*>(vp) = o;
+        } else {        // local channel tch: half tch >> 2, step tch & 3; patch tid & 31
+            VB[buf * VST + F * 256 + ((tch >> 2) * 32 + (tid & 31)) * 4 + (tch & 3)] = vv[0][F];
+        }
     };
     auto b_read = [&](int buf, auto f_) {
         constexpr int F = decltype(f_)::value;
-        const f32x4 t = *reinterpret_cast<const f32x4*>(VB + buf * WINO_SLAB + (lh * 64 + wn * 32 + l31) * 4 + F * 512);
+        const f32x4 t = *reinterpret_cast<const f32x4*>(VB + buf * VST + (lh * TW + wn * 32 + l31) * 4 + F * (8 * TW));
         bq[F & 1][0] = t[0]; bq[F & 1][1] = t[1]; bq[F & 1][2] = t[2]; bq[F & 1][3] = t[3];
     };
 #define IC(n) std::integral_constant<int, (n)>{}
@@ -357,7 +375,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_kernel(const ConvKArgs a)
     const int p00 = oy * W + ox;
     unsigned gwl[4] = {0u, 0u, 0u, 0u};
     {
-        const int cw = cg * WINO_CO + wm * 32;
+        const int cw = co_w;
         const bool fst = cw < a.co1;
         const unsigned* gmx = fst ? a.ymask1 : a.ymask2;
         if (gmx && row1 && cw + 32 <= a.cout) {
@@ -424,8 +442,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_kernel(const ConvKArgs a)
     // the wave's 32 channels exist and go to one output tensor, no sigmoid.  Scalar row bases + one 32-bit lane offset:
     // no per-store address arithmetic, no per-value predicates; a value already in y1 (accumulate_y1) is requested for
     // all 16 rows before the first one is needed.
-    const int co_w = cg * WINO_CO + wm * 32;
-    const bool fast = !sigmoid && t0 + WINO_TILES <= ntiles && (H & 1) == 0 && co_w + 32 <= a.cout &&
+    const bool fast = !sigmoid && t0 + TW <= ntiles && (H & 1) == 0 && co_w + 32 <= a.cout &&
                       (co_w + 32 <= a.co1 || co_w >= a.co1) && WINO_ABL != 5;
     if (fast) {
         typedef __attribute__((address_space(1))) char* gwp;
@@ -471,7 +488,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_kernel(const ConvKArgs a)
                 o[1] = s0[1] - s0[2] - s0[3];
                 o[2] = s1[0] + s1[1] + s1[2];
                 o[3] = s1[1] - s1[2] - s1[3];
-                const float badd = BIASL[wm * 32 + rowu + 4 * lh];
+                const float badd = BIASL[co_l + rowu + 4 * lh];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float u = fmaf(o[q], sc, badd);
@@ -490,7 +507,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_kernel(const ConvKArgs a)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) bits[q] |= __shfl_xor(bits[q], 32);
                 const int nw = (a.cout + 31) >> 5;
-                gwp mrow = (gwp)(a.mask_out) + ((size_t)b * nw + (cg * 2 + wm)) * plane_b;
+                gwp mrow = (gwp)(a.mask_out) + ((size_t)b * nw + (co_w >> 5)) * plane_b;
                 if (lh == 0) {
                     u32x2w v0 = {bits[0], bits[1]}, v1 = {bits[2], bits[3]};
                     *(gm2)(mrow + p00 * 4) = v0;
@@ -506,7 +523,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_kernel(const ConvKArgs a)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int co = cg * WINO_CO + wm * 32 + row;
+        const int co = co_w + row;
         float m[16];
 #pragma unroll
         for (int f = 0; f < 16; ++f) m[f] = acc[f][r];
@@ -521,7 +538,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_kernel(const ConvKArgs a)
         o[1] = s0[1] - s0[2] - s0[3];
         o[2] = s1[0] + s1[1] + s1[2];
         o[3] = s1[1] - s1[2] - s1[3];
-        const float badd = BIASL[wm * 32 + row];
+        const float badd = BIASL[co_l + row];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float u = o[q] * sc + badd;
@@ -566,7 +583,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_kernel(const ConvKArgs a)
     if (a.mask_out) {         // wave-uniform: the 1-bit leaky-relu gate of this wave's 32 channels
 #pragma unroll
         for (int q = 0; q < 4; ++q) bits[q] |= __shfl_xor(bits[q], 32);
-        const int nw = (a.cout + 31) >> 5, w = cg * 2 + wm;
+        const int nw = (a.cout + 31) >> 5, w = co_w >> 5;
         if (lh == 0 && tvalid && w < nw) {
             unsigned* dst = a.mask_out + ((size_t)b * nw + w) * HW + p00;
             if (vec) {
@@ -668,10 +685,10 @@ extern "C" int scm_pack_conv3x3_weights_wino(const float* w, int cin, int cout, 
     return SCM_OK;
 }
 
-template <int NJ, int GATED, int PADC>
+template <int NJ, int GATED, int PADC, int CW>
 static int launch_wino(const ConvKArgs& a, int groups, hipStream_t s) {
-    const size_t lds = ((size_t)KC * NJ * 512 + 2 * WINO_SLAB + WINO_CO) * sizeof(float);
-    auto kern = conv3x3_wino_kernel<NJ, GATED, PADC>;
+    const size_t lds = ((size_t)KC * NJ * 512 + 2 * 128 * (CW == 64 ? 64 : 32) + CW) * sizeof(float);
+    auto kern = conv3x3_wino_kernel<NJ, GATED, PADC, CW>;
     static std::atomic<uint64_t> attr_done{0};       // per (instantiation, device)
     if (int rc = scm_ensure_lds_attr(reinterpret_cast<const void*>(kern), attr_done, 160 * 1024)) return rc;
     dim3 grid(a.B * a.tiles_per_img, groups);
@@ -680,16 +697,16 @@ static int launch_wino(const ConvKArgs& a, int groups, hipStream_t s) {
     return SCM_OK;
 }
 
-// halo elements per channel of the worst workgroup (64 consecutive tiles of a TCW-wide tile grid; raw rows of W + 4)
-static inline int wino_plane(int H, int W) {
+// halo elements per channel of the worst workgroup (tw consecutive tiles of a TCW-wide tile grid; raw rows of W + 6)
+static inline int wino_plane(int H, int W, int tw) {
     const int tcw = W / 2, trh = (H + 1) / 2;
-    int trows = (WINO_TILES % tcw == 0) ? WINO_TILES / tcw : (WINO_TILES + tcw - 2) / tcw + 1;
+    int trows = (tw % tcw == 0) ? tw / tcw : (tw + tcw - 2) / tcw + 1;
     if (trows > trh) trows = trh;
     return (2 * trows + 2) * (W + 6);
 }
 
 extern "C" int scm_conv3x3_wino_serves(int H, int W) {
-    return H >= 2 && W >= 2 && (W & 1) == 0 && wino_plane(H, W) <= 2 * 512;
+    return H >= 2 && W >= 2 && (W & 1) == 0 && wino_plane(H, W, WINO_TILES) <= 2 * 512;
 }
 
 extern "C" int scm_conv3x3_wino(const scm_conv3x3_desc* d, void* stream) {
@@ -732,16 +749,23 @@ extern "C" int scm_conv3x3_wino(const scm_conv3x3_desc* d, void* stream) {
                   reinterpret_cast<size_t>(d->gate_mask_out)) & 7) == 0,
                 "scm_conv3x3_wino: tensors must be 8-byte aligned");
     const int ntiles = ((d->H + 1) / 2) * (d->W / 2);
-    k.tiles_per_img = (ntiles + WINO_TILES - 1) / WINO_TILES;
-    k.plane = wino_plane(d->H, d->W);
-    const int groups = (d->cout + WINO_CO - 1) / WINO_CO;
+    // 128 output channels per workgroup (half the transform and staging work per MFMA) where the layer has whole
+    // 128-channel groups, one output tensor per group and the patch rows tile 32 patches
+    static const int no128 = getenv("SCM_WINO_NO128") ? atoi(getenv("SCM_WINO_NO128")) : 0;
+    const int tcw = d->W / 2;
+    const bool cw128 = !no128 && (d->cout & 127) == 0 && (d->co1 & 31) == 0 && tcw <= 32 && 32 % tcw == 0 && ntiles % 32 == 0;
+    const int tw = cw128 ? 32 : WINO_TILES;
+    k.tiles_per_img = (ntiles + tw - 1) / tw;
+    k.plane = wino_plane(d->H, d->W, tw);
+    const int groups = cw128 ? d->cout / 128 : (d->cout + WINO_CO - 1) / WINO_CO;
     hipStream_t s = (hipStream_t)stream;
     const int g = d->gate_act == 0 ? 0 : ((d->gate_mask_in && d->gate_act == SCM_ACT_LRELU && d->c2 == 0) ? 2 : 1);
     const bool circ = d->pad_mode == SCM_PAD_CIRCULAR;
-#define SCM_WINO_P(NJ_, G_) (circ ? launch_wino<NJ_, G_, 1>(k, groups, s) : launch_wino<NJ_, G_, 0>(k, groups, s))
-#define SCM_WINO_G(NJ_) (g == 2 ? SCM_WINO_P(NJ_, 2) : (g == 1 ? SCM_WINO_P(NJ_, 1) : SCM_WINO_P(NJ_, 0)))
-    if (k.plane <= 512) return SCM_WINO_G(1);
-    return SCM_WINO_G(2);
+#define SCM_WINO_P(NJ_, G_, CW_) (circ ? launch_wino<NJ_, G_, 1, CW_>(k, groups, s) : launch_wino<NJ_, G_, 0, CW_>(k, groups, s))
+#define SCM_WINO_G(NJ_, CW_) (g == 2 ? SCM_WINO_P(NJ_, 2, CW_) : (g == 1 ? SCM_WINO_P(NJ_, 1, CW_) : SCM_WINO_P(NJ_, 0, CW_)))
+    if (cw128) return SCM_WINO_G(1, 128);          // (W <= 64: the raw rows of 32 patches fit one pair per thread)
+    if (k.plane <= 512) return SCM_WINO_G(1, 64);
+    return SCM_WINO_G(2, 64);
 #undef SCM_WINO_G
 #undef SCM_WINO_P
 }
