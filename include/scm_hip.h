@@ -359,6 +359,10 @@ size_t scm_conv3x3_pack_wino_floats(int cin, int cout);
 int scm_pack_conv3x3_weights_wino(const float* w, int cin, int cout, int transposed_src, int w_cin_total, int w_ci0,
                                   float* fwd_pack, float* dgrad_pack, void* stream);
 int scm_conv3x3_wino_serves(int H, int W);
+/* Layers with <= 16 output channels (Transition.conv6, Encoder.conv4, the input gradient of Transition.conv1) have their
+ * own form on the 16-row MFMA: the pack functions choose its layout for such a direction, scm_conv3x3_wino takes it for
+ * ungated inputs, one output tensor and no accumulate on frames scm_conv3x3_wino16_serves accepts. */
+int scm_conv3x3_wino16_serves(int H, int W);
 int scm_conv3x3_wino(const scm_conv3x3_desc* d, void* stream);
 /* Weight / bias gradient (scm_conv3x3_wgrad's descriptor, workspaces and reduce) by the same algorithm:
  * dL/dg = G^T [ sum over 2x2 output patches of (A dY A^T) .* (B^T d B) ] G.  Serves layers with >= 48 channels on both

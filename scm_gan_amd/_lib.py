@@ -154,6 +154,7 @@ def lib():
             "scm_conv3x3_wino": [vp, vp],
             "scm_conv3x3_wgrad_wino": [vp, vp],
             "scm_conv3x3_wino_serves": [ci, ci],
+            "scm_conv3x3_wino16_serves": [ci, ci],
             "scm_decoder_fused_pack_floats": [],
             "scm_decoder_fused_pack": [vp, vp, vp, vp, ci, ci, vp, vp],
             "scm_decoder_fused_workspace": [ci, ci, ci, ci, vp, vp],

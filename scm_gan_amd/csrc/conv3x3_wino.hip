@@ -662,6 +662,7 @@ __global__ void pack_conv3x3_wino_kernel(const float* __restrict__ w, int cin, i
 // ------------------------------------------------------------------ host
 extern "C" size_t scm_conv3x3_pack_wino_floats(int cin, int cout) {
     if (cin <= 0 || cout <= 0) return 0;
+    if (cout <= 16) return scm_wino16_pack_floats(cin);          // the 16-row kernel's layout (conv3x3_wino16.hip)
     return (size_t)((cout + WINO_CO - 1) / WINO_CO) * ((cin + KC - 1) / KC) * WINO_SLAB;
 }
 
@@ -671,6 +672,15 @@ extern "C" int scm_pack_conv3x3_weights_wino(const float* w, int cin, int cout, 
     if (w_cin_total == 0) w_cin_total = cin;
     SCM_REQUIRE(w_ci0 >= 0 && w_ci0 + cin <= w_cin_total, "scm_pack_conv3x3_weights_wino: bad channel slice");
     SCM_REQUIRE(fwd_pack || dgrad_pack, "scm_pack_conv3x3_weights_wino: no output requested");
+    // a direction with <= 16 output channels gets the 16-row kernel's pack
+    const bool f16 = fwd_pack && cout <= 16, d16 = dgrad_pack && cin <= 16;
+    if (f16 || d16) {
+        if (int rc = scm_pack_wino16(w, cin, cout, transposed_src, w_cin_total, w_ci0, f16 ? fwd_pack : nullptr,
+                                     d16 ? dgrad_pack : nullptr, (hipStream_t)stream)) return rc;
+        if (f16) fwd_pack = nullptr;
+        if (d16) dgrad_pack = nullptr;
+        if (!fwd_pack && !dgrad_pack) return SCM_OK;
+    }
     size_t n = 0;
     if (fwd_pack) n = scm_conv3x3_pack_wino_floats(cin, cout) / 16;
     if (dgrad_pack) {
@@ -705,6 +715,8 @@ static inline int wino_plane(int H, int W, int tw) {
     return (2 * trows + 2) * (W + 6);
 }
 
+extern "C" int scm_conv3x3_wino16_serves(int H, int W) { return scm_wino16_serves(H, W) ? 1 : 0; }
+
 extern "C" int scm_conv3x3_wino_serves(int H, int W) {
     return H >= 2 && W >= 2 && (W & 1) == 0 && wino_plane(H, W, WINO_TILES) <= 2 * 512;
 }
@@ -722,6 +734,26 @@ extern "C" int scm_conv3x3_wino(const scm_conv3x3_desc* d, void* stream) {
     SCM_REQUIRE(d->act >= 0 && d->act <= 2 && d->gate_act >= 0 && d->gate_act <= 2, "scm_conv3x3_wino: bad act");
     if (d->gate_act) {
         SCM_REQUIRE(d->gate1 && (d->c2 == 0 || d->gate2), "scm_conv3x3_wino: gate tensors required with gate_act");
+    }
+    if (d->cout <= 16) {
+        // the 16-row kernel (conv3x3_wino16.hip): ungated input, one output tensor, plain store
+        if (d->gate_act || d->accumulate_y1 || d->gate_mask_y1 || d->gate_mask_y2 || d->gate_mask_out || d->co1 != d->cout ||
+            !scm_wino16_serves(d->H, d->W) || (d->c2 != 0 && (d->c1 & 7) != 0) ||
+            ((reinterpret_cast<size_t>(d->x1) | reinterpret_cast<size_t>(d->x2) | reinterpret_cast<size_t>(d->y1)) & 7)) {
+            scm_set_error("scm_conv3x3_wino: the 16-channel form takes ungated inputs, one plain output tensor and frames "
+                          "scm_conv3x3_wino16_serves accepts (%dx%d)", d->H, d->W);
+            return SCM_EUNSUPPORTED;
+        }
+        ConvKArgs k16;
+        k16.x1 = d->x1; k16.x2 = d->x2; k16.c1 = d->c1; k16.c2 = d->c2;
+        k16.gate1 = k16.gate2 = nullptr; k16.gate_act = 0;
+        k16.wpack = d->wpack; k16.cout = d->cout;
+        k16.scale = d->scale; k16.bias = d->bias; k16.sbias = d->sbias;
+        k16.y1 = d->y1; k16.y2 = nullptr; k16.co1 = d->cout;
+        k16.B = d->B; k16.H = d->H; k16.W = d->W; k16.pad_mode = d->pad_mode; k16.act = d->act;
+        k16.mask_in = nullptr; k16.mask_out = nullptr; k16.acc_y1 = 0; k16.ymask1 = k16.ymask2 = nullptr;
+        k16.tiles_per_img = 0; k16.plane = 0;
+        return scm_launch_wino16(k16, (hipStream_t)stream);
     }
     if (!scm_conv3x3_wino_serves(d->H, d->W)) {
         scm_set_error("scm_conv3x3_wino: frame %dx%d does not fit the halo staging map (scm_conv3x3_wino_serves)", d->H,

@@ -22,3 +22,10 @@ struct ConvKArgs {
 
 // cout <= 16 variant on v_mfma_f32_16x16x4_f32 (conv3x3_m16.hip)
 int scm_launch_conv3x3_m16(const ConvKArgs& k, hipStream_t s);
+
+// cout <= 16 Winograd variant on v_mfma_f32_16x16x4_f32 (conv3x3_wino16.hip): pack size / builder, frame check, launch
+size_t scm_wino16_pack_floats(int cin);
+int scm_pack_wino16(const float* w, int cin, int cout, int transposed_src, int w_cin_total, int w_ci0, float* fwd_pack,
+                    float* dgrad_pack, hipStream_t s);
+bool scm_wino16_serves(int H, int W);
+int scm_launch_wino16(const ConvKArgs& k, hipStream_t s);

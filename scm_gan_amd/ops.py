@@ -114,6 +114,13 @@ def set_conv_algo(name):
 set_conv_algo(_conv_algo[0])
 
 
+WINO16 = os.environ.get("SCM_NO_WINO16", "0") in ("", "0")
+
+
+def wino16_serves(H, W):
+    return bool(L.lib().scm_conv3x3_wino16_serves(H, W))
+
+
 def pack_mode():
     """What a cached weight pack depends on besides the weights: (operand precision, fp32 algorithm)."""
     return (_precision[0], _conv_algo[0])
@@ -158,8 +165,9 @@ def pack_conv3x3(weight, cin, cout, transposed=False, cin_total=0, ci0=0):
     if _conv_algo[0] == "winograd":
         # transformed-filter packs for the directions wide enough on both sides; the native packs stay as the
         # per-call fallback for frames the kernel does not take (wino_serves)
-        fwd_w = cout >= WINO_MIN_COUT and cin >= WINO_MIN_CIN
-        dgr_w = cin >= WINO_MIN_COUT and cout >= WINO_MIN_CIN
+        # (<= 16 output channels: the 16-row form, scm_conv3x3_wino16_serves; from 32 input channels on)
+        fwd_w = (cout >= WINO_MIN_COUT and cin >= WINO_MIN_CIN) or (cout <= 16 and cin >= 32 and WINO16)
+        dgr_w = (cin >= WINO_MIN_COUT and cout >= WINO_MIN_CIN) or (cin <= 16 and cout >= 32 and WINO16)
         if fwd_w or dgr_w:
             fx = _new(w, lib.scm_conv3x3_pack_wino_floats(cin, cout)) if fwd_w else None
             dx = _new(w, lib.scm_conv3x3_pack_wino_floats(cout, cin)) if dgr_w else None
@@ -379,10 +387,11 @@ class Conv3x3Fn(Function):
         if ALGO_WINO in (fprec, dprec):
             # frames / operand layouts the Winograd kernels do not take run the direct kernels (native packs)
             frame_ok = wino_serves(H, W)
-            if fprec == ALGO_WINO and not (frame_ok and (c2 == 0 or c1 % 8 == 0) and x1.data_ptr() % 8 == 0
+            f_ok = wino16_serves(H, W) if cout <= 16 else frame_ok
+            if fprec == ALGO_WINO and not (f_ok and (c2 == 0 or c1 % 8 == 0) and x1.data_ptr() % 8 == 0
                                            and (x2 is None or x2.data_ptr() % 8 == 0)):
                 fpack, fprec = cfg["packs"][4], PREC_F32
-            if dprec == ALGO_WINO and not frame_ok:
+            if dprec == ALGO_WINO and not (wino16_serves(H, W) if c1 + c2 <= 16 else frame_ok):
                 dpack, dprec = cfg["packs"][5], PREC_F32
         sbias = None
         if act_vec is not None:
@@ -431,6 +440,8 @@ class Conv3x3Fn(Function):
             dprec = ctx.dprec
             if dprec == ALGO_WINO and (gy.data_ptr() | y.data_ptr()) % 8:
                 dpack, dprec = cfg["packs"][5], PREC_F32          # (an oddly offset gradient view: direct kernel)
+            if dprec == ALGO_WINO and c1 + c2 <= 16 and (act or acc1 is not None or c2):
+                dpack, dprec = cfg["packs"][5], PREC_F32          # (the 16-row form takes ungated, plain-store launches)
             if (in_masks[0] is not None or in_masks[1] is not None) and dprec != ALGO_WINO:
                 raise RuntimeError("scm_gan_amd.conv3x3.backward: producer-side gating needs the Winograd input-gradient "
                                    "kernel (ops.pregate_ok)")

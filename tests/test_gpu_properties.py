@@ -197,7 +197,10 @@ def test_gate_mask_is_the_sign_of_y_and_gives_identical_gradients(B, cin, cout, 
         x = torch.randn(B, cin, H, W, device="cuda")
         w = torch.randn(cout, cin, 3, 3, device="cuda") * 0.05
         bias = torch.randn(cout, device="cuda") * 0.1
-        fp, dp, fprec, dprec = ops.pack_conv3x3(w, cin, cout)[:4]      # (the default fp32 algorithm: Winograd where it serves)
+        packs = ops.pack_conv3x3(w, cin, cout)      # (the default fp32 algorithm: Winograd where it serves)
+        fp, dp, fprec, dprec = packs[:4]
+        if dprec == ops.ALGO_WINO and cin <= 16:        # the 16-channel Winograd form takes ungated launches only: as the
+            dp, dprec = packs[5], ops.PREC_F32          # layer code does, a gated one runs the direct kernel
         nw = (cout + 31) // 32
         mask = torch.zeros(B, nw, H, W, device="cuda", dtype=torch.int32)
         y, _ = ops._conv3x3_raw(x, None, None, None, 0, fp, cout, None, bias, None, cout, circ, ops.ACT_LRELU, fprec,

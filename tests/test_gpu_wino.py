@@ -123,26 +123,54 @@ def test_forward_and_input_gradient_vs_float64(K, B, c1, c2, cout, H, W, pad, ac
             want[:, -1] &= keep
         assert torch.equal(got, want)
     # input gradient: dx = conv(dy * lrelu'(y), dgrad pack), split into dx1 / dx2 with dx1 accumulated into a buffer;
-    # float gate and 1-bit gate
+    # float gate and 1-bit gate.  A gradient with <= 16 channels is the 16-row form's (conv3x3_wino16.hip): ungated,
+    # one plain output -- what the layer code sends it (a gated one runs the direct kernel).
+    thin = c1 + c2 <= 16
     xin_r = xin.double().requires_grad_(True)
-    yr2 = ref_conv(xin_r, w.double(), None, pad, 1)
+    yr2 = ref_conv(xin_r, w.double(), None, pad, 0 if thin else 1)
     dy = torch.randn_like(yr2)
     yr2.backward(dy)
     yf = yr2.detach().float().cuda()
-    for mode in ("float", "mask"):
+    for mode in (("none",) if thin else ("float", "mask")):
         if mode == "mask" and cout <= 32:
             continue
         e = {}
         for wino in (1, 0):
             _, dp = K.pack(w.cuda(), wino)
-            base = torch.randn(B, c1, H, W, device="cuda") if c2 else None
-            dx1, dx2 = K.conv(wino, dy.float().cuda(), None, dp, c1 + c2, pad, 0, gate1=yf, gate_act=1, co1=c1 if c2 else None,
+            base = torch.randn(B, c1, H, W, device="cuda") if (c2 and not thin) else None
+            dx1, dx2 = K.conv(wino, dy.float().cuda(), None, dp, c1 + c2, pad, 0, gate1=None if thin else yf,
+                              gate_act=0 if thin else 1, co1=c1 if (c2 and not thin) else None,
                               mask_in=mask_words(yf) if mode == "mask" else None, y1_acc=None if base is None else base.clone())
             if base is not None:
                 dx1 = dx1 - base
             dx = dx1 if dx2 is None else torch.cat([dx1, dx2], 1)
             e[wino] = float((dx.cpu().double() - xin_r.grad).abs().max())
         assert e[1] < 2e-5 and e[1] <= 2.0 * e[0] + 1e-7, (mode, e)
+
+
+THIN = [  # B, c1, c2, cout <= 16, H, W, circular, act: the 16-row form's forward
+    (2, 128, 128, 16, 16, 16, 1, 2), (2, 128, 0, 16, 16, 16, 0, 2), (1, 40, 0, 16, 20, 12, 1, 0), (2, 64, 0, 3, 9, 8, 0, 1),
+    (1, 128, 128, 16, 64, 64, 1, 2), (1, 32, 0, 16, 128, 128, 0, 0), (1, 32, 8, 12, 33, 22, 1, 2), (3, 128, 0, 16, 32, 32, 1, 0)]
+
+
+@pytest.mark.parametrize("B,c1,c2,cout,H,W,pad,act", THIN)
+def test_sixteen_channel_form_vs_float64(K, B, c1, c2, cout, H, W, pad, act):
+    """conv3x3_wino16.hip (v_mfma_f32_16x16x4_f32; Transition.conv6, Encoder.conv4): forward with scale, bias and every
+    activation against float64, next to the direct 16-row kernel."""
+    assert K.lib.scm_conv3x3_wino16_serves(H, W) == 1
+    torch.manual_seed(2)
+    x1 = torch.randn(B, c1, H, W)
+    x2 = torch.randn(B, c2, H, W) if c2 else None
+    w, b, sc = torch.randn(cout, c1 + c2, 3, 3) * 0.05, torch.randn(cout), torch.tensor([0.7])
+    xin = x1 if x2 is None else torch.cat([x1, x2], 1)
+    yr = ref_conv(xin.double(), w.double() * 0.7, b.double(), pad, act)
+    err = {}
+    for wino in (1, 0):
+        fp, _ = K.pack(w.cuda(), wino)
+        y, _ = K.conv(wino, x1.cuda(), None if x2 is None else x2.cuda(), fp, cout, pad, act, bias=b.cuda(), scale=sc.cuda())
+        err[wino] = float((y.cpu().double() - yr).abs().max())
+    assert err[1] < 1e-5 and err[1] <= 2.0 * err[0] + 1e-7, err
+    assert K.lib.scm_conv3x3_wino16_serves(84, 84) == 0          # (its 128-patch rows do not fit: the direct kernel runs)
 
 
 @pytest.mark.parametrize("B,c1,c2,cout,H,W,pad,act", WSHAPES)

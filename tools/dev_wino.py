@@ -150,7 +150,7 @@ def timing():
             res[0], fl / res[0] / 1e6, res[1], fl / res[1] / 1e6, res[1] / res[0]))
 
 
-if __name__ == '__main__' and 'wgrad' not in sys.argv:
+if __name__ == '__main__' and 'wgrad' not in sys.argv and 'w16' not in sys.argv:
     ok = check()
     if ok or 'time' in sys.argv:
         timing()
@@ -242,3 +242,66 @@ if __name__ == '__main__' and 'wgrad' in sys.argv:
     ok = check_wgrad()
     if ok or 'time' in sys.argv:
         timing_wgrad()
+
+
+# ---------------------------------------------------------------- 16-output-channel form
+def check_w16():
+    torch.manual_seed(2)
+    ok = True
+    for (B, c1, c2, cout, H, W, pad, act) in [
+            (2, 128, 128, 16, 16, 16, 1, 2), (2, 128, 0, 16, 16, 16, 0, 2), (1, 40, 0, 16, 20, 12, 1, 0), (2, 64, 0, 3, 9, 8, 0, 1),
+            (1, 128, 128, 16, 64, 64, 1, 2), (1, 32, 0, 16, 128, 128, 0, 0), (1, 32, 8, 12, 33, 22, 1, 2), (1, 48, 0, 16, 84, 84, 1, 0),
+            (3, 128, 0, 16, 32, 32, 1, 0)]:
+        if not lib.scm_conv3x3_wino16_serves(H, W):
+            print('w16', (H, W), 'not served'); continue
+        x1 = torch.randn(B, c1, H, W); x2 = torch.randn(B, c2, H, W) if c2 else None
+        w = torch.randn(cout, c1 + c2, 3, 3) * 0.05; b = torch.randn(cout); sc = torch.tensor([0.7])
+        xin = x1 if x2 is None else torch.cat([x1, x2], 1)
+        yr = ref_conv(xin.double(), w.double() * 0.7, b.double(), pad, act)
+        errs = []
+        for wino in (1, 0):
+            fp, dp = pack(w.to(dev), wino)
+            y, _ = conv(wino, x1.to(dev), None if x2 is None else x2.to(dev), fp, cout, pad, act, bias=b.to(dev), scale=sc.to(dev))
+            errs.append((y.cpu().double() - yr).abs().max().item())
+        # input gradient of a (c1+c2 <- cout) layer seen from the other side: dy has c1 channels, dx has cout <= 16
+        w2 = torch.randn(c1, cout, 3, 3) * 0.05           # layer cout -> c1
+        xr = torch.randn(B, cout, H, W).double().requires_grad_(True)
+        y2 = ref_conv(xr, w2.double(), None, pad, 0)
+        dy = torch.randn_like(y2)
+        y2.backward(dy)
+        e2 = []
+        for wino in (1, 0):
+            fp, dp = pack(w2.to(dev), wino)
+            dx, _ = conv(wino, dy.float().to(dev), None, dp, cout, pad, 0)
+            e2.append((dx.cpu().double() - xr.grad).abs().max().item())
+        print('w16', (B, c1, c2, cout, H, W, pad, act), 'fwd err wino %.3e direct %.3e | dgrad err wino %.3e direct %.3e' % (errs[0], errs[1], e2[0], e2[1]))
+        ok &= errs[0] < 2e-5 and e2[0] < 2e-5
+    print('W16 ALL OK' if ok else 'W16 FAILED')
+    return ok
+
+
+def timing_w16():
+    for (B, c1, c2, cout, H, W, act) in [(64, 128, 128, 16, 64, 64, 2), (64, 128, 0, 16, 64, 64, 0), (8, 128, 128, 16, 64, 64, 2),
+                                         (16, 128, 128, 16, 128, 128, 2)]:
+        x1 = torch.randn(B, c1, H, W, device=dev); x2 = torch.randn(B, c2, H, W, device=dev) if c2 else None
+        w = torch.randn(cout, c1 + c2, 3, 3, device=dev) * 0.05; b = torch.randn(cout, device=dev)
+        res = []
+        for wino in (1, 0):
+            fp, dp = pack(w, wino)
+            for _ in range(3): conv(wino, x1, x2, fp, cout, 1, act, bias=b)
+            torch.cuda.synchronize()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            n = 10
+            s.record()
+            for _ in range(n): conv(wino, x1, x2, fp, cout, 1, act, bias=b)
+            e.record(); torch.cuda.synchronize()
+            res.append(s.elapsed_time(e) / n * 1e3)
+        fl = 2.0 * B * H * W * cout * (c1 + c2) * 9
+        print('w16 time', (B, c1, c2, cout, H, W), 'wino %.1f us (%.1f TF algorithmic)  direct %.1f us (%.1f TF)  x%.2f' % (
+            res[0], fl / res[0] / 1e6, res[1], fl / res[1] / 1e6, res[1] / res[0]))
+
+
+if __name__ == '__main__' and 'w16' in sys.argv:
+    ok = check_w16()
+    if ok or 'time' in sys.argv:
+        timing_w16()
