@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wgrad_wino_kernel(const WgradK
     const unsigned mch = (unsigned)(coc >> 5) * (unsigned)plane_b;
     const unsigned mbit = 1u << (coc & 31);
     const float chv = co < a.cout ? 1.f : 0.f;
-    auto vo = [](unsigned o) { asm volatile("" : "+v"(o)); return o; };
+    auto vo = [](unsigned o) { return o; };       // (the lane offsets are laundered in place, once per chunk: ld_setup)
 
     f32x16 acc[16];
 #pragma unroll
@@ -151,6 +151,9 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wgrad_wino_kernel(const WgradK
         }
         l_xe = xch + ixe * 4; l_xm = xch + ixm * 4;
         l_dm = dch + ixm * 4; l_mm = mch + ixm * 4;
+        // (keeps the zero-extension of the offsets next to the loads: scalar-base addressing without a copy per load)
+        asm volatile("" : "+v"(l_xe), "+v"(l_xm), "+v"(l_dm), "+v"(l_mm));
+        if constexpr (EDGE) asm volatile("" : "+v"(l_xe2));
     };
     auto xrow_base = [&](int ty, int i) {
         int iy = 2 * ty - 1 + i;

@@ -183,9 +183,10 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_kernel(const ConvKArgs a)
     float vv[2][16];
 
     auto clampc = [&](int chunk) { return chunk < nchunk ? chunk : nchunk - 1; };
-    // (a 32-bit offset laundered through an empty asm in the block that uses it keeps its zero-extension next to the
-    // load, which is what lets instruction selection fold it into the scalar-base addressing mode)
-    auto vo = [](unsigned o) { asm volatile("" : "+v"(o)); return o; };
+    // (32-bit lane offsets are laundered IN PLACE through an empty asm once per chunk -- launder() -- so that their
+    // zero-extension stays inside the loop, next to the loads, where instruction selection folds it into the
+    // scalar-base addressing mode; a per-load laundering copy costs a v_mov each)
+    auto vo = [](unsigned o) { return o; };
     // A operands of position F of `chunk` (clamped: past the end the last slab is re-read and never used)
     auto u_load = [&](int chunk, auto fc) {
         constexpr int F = decltype(fc)::value;
@@ -416,6 +417,9 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_kernel(const ConvKArgs a)
     WINO_TICK(0);
     for (int chunk = 0; chunk < nchunk; ++chunk) {
         const int cur = chunk & 1;
+        asm volatile("" : "+v"(uoff[0]), "+v"(uoff[1]), "+v"(uoff[2]), "+v"(uoff[3]));
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(poff[j]));
         if (WINO_ABL < 4) b_read(cur, IC(0));
         SB();
         slot(chunk, cur, IC(0)); slot(chunk, cur, IC(1)); slot(chunk, cur, IC(2)); slot(chunk, cur, IC(3));

@@ -3,6 +3,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DWINO_TIMING=300 -I scm_gan_amd/csrc -I include tools/exp/wino_phases.hip \
 //         -o tools/exp/bin/wino_phases
 #include "../../scm_gan_amd/csrc/conv3x3_wino.hip"
+#include "../../scm_gan_amd/csrc/conv3x3_wino16.hip"      // (the entry point dispatches the 16-channel form)
 #include <cstdio>
 #include <vector>
 
