@@ -269,7 +269,7 @@ def measured_traffic(kernel_name):
     src = {"h16": "conv3x3_h16.hip", "x3": "conv3x3_x3.hip", "mfma": "conv3x3_mfma.hip", "wino": "conv3x3_wino.hip"}[kind]
     sha = _sha16(os.path.join(ROOT, "scm_gan_amd", "csrc", src))
     want = {"h16": "conv3x3_h16_kernel<1,", "x3": "conv3x3_x3_kernel<2, 2, 0,", "mfma": "conv3x3_mfma_kernel<4, 2, 2, 0,",
-            "wino": "conv3x3_wino_kernel<1, 0, 1>"}[kind]
+            "wino": "conv3x3_wino_kernel<1, 0, 1, 128>"}[kind]
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_pmc*.json")), reverse=True):
         try:
             pmc = json.load(open(f))

@@ -646,6 +646,9 @@ static int wgrad_impl(const scm_conv3x3_wgrad_desc* d, int precision, void* stre
     if (precision == SCM_ALGO_WINO && d->cout >= 48 && cin >= 48 && scm_wgrad_wino_serves(a)) {
         // Winograd F(2x2,3x3) on the f32 MFMA pipe (conv3x3_wgrad_wino.hip); same slabs, its own (coarser) split
         rc = scm_launch_wgrad_wino(a, p.nsplit, &p.nsplit, &p.spi, s);
+    } else if (precision == SCM_ALGO_WINO && p.m16 && scm_wgrad_wino16_serves(a, p.nsplit)) {
+        // the same algorithm for the 16-channel-side layers (conv3x3_wgrad_wino16.hip)
+        rc = scm_launch_wgrad_wino16(a, p.nsplit, &p.nsplit, &p.spi, s);
     } else if (precision == SCM_ALGO_WINO) {
         return wgrad_impl(d, SCM_PREC_F32, stream);          // shapes it does not take: the direct kernels
     } else if (precision == SCM_PREC_BF16X3 && d->cout > 64 && p.m16 == 0 && p.mt == 4) {

@@ -44,6 +44,7 @@ typedef unsigned u32x2w __attribute__((ext_vector_type(2)));
 // of wave 0 of one workgroup: prologue, K loop, epilogue.
 #ifdef WINO_TIMING
 __device__ unsigned long long wino_ticks[4];
+__device__ unsigned long long wino_trace[3 * 8192];     // per workgroup: (XCC_ID << 32 | HW_ID), entry clock, exit clock
 #define WINO_TICK(i)                                    \
     do {                                                \
         const unsigned long long t_ = clock64();        \
@@ -66,6 +67,9 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_kernel(const ConvKArgs a)
     constexpr int VST = 128 * TW;                     // floats of one V stage [16][2][TW][4]
     float* const VB = smem + KC * PLANE;              // two stages of V
     float* const BIASL = VB + 2 * VST;                // [CW]
+#ifdef WINO_TIMING
+    const unsigned long long t_entry = clock64();
+#endif
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -610,6 +614,14 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_kernel(const ConvKArgs a)
     WINO_TICK(2);
     if (blockIdx.x == WINO_TIMING && blockIdx.y == 0 && tid == 0)
         for (int i = 0; i < 4; ++i) wino_ticks[i] = t_acc[i];
+    __syncthreads();
+    const unsigned wg_ = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (tid == 0 && wg_ < 8192) {
+        wino_trace[3 * wg_] = ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32) |
+                              __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        wino_trace[3 * wg_ + 1] = t_entry;
+        wino_trace[3 * wg_ + 2] = clock64();
+    }
 #endif
 }
 

@@ -28,3 +28,8 @@ int scm_launch_wgrad_x3(const WgradKArgs& a, const WgradPlan& p, hipStream_t s);
 #define SCM_ALGO_WINO 16
 bool scm_wgrad_wino_serves(const WgradKArgs& a);
 int scm_launch_wgrad_wino(const WgradKArgs& a, int max_splits, int* nsplit_out, int* spi_out, hipStream_t s);
+
+// Winograd F(2x2,3x3) weight gradient of the layers with at most 16 channels on one side, 16 x 16 tiles on
+// v_mfma_f32_16x16x4_f32 with operands transformed in the lanes that feed them (conv3x3_wgrad_wino16.hip).
+bool scm_wgrad_wino16_serves(const WgradKArgs& a, int max_splits);
+int scm_launch_wgrad_wino16(const WgradKArgs& a, int max_splits, int* nsplit_out, int* spi_out, hipStream_t s);

@@ -196,6 +196,42 @@ def test_weight_gradient_vs_float64(K, B, c1, c2, cout, H, W, pad, act):
         assert max(e[1]) < 2e-6 and e[1][0] <= 3.0 * e[0][0] + 1e-8, (mode, e)
 
 
+WTHIN = [  # B, c1, c2, cout, H, W, circular, act: at most 16 channels on one side (conv3x3_wgrad_wino16.hip), and shapes
+    # it hands to the direct kernel (W % 32 != 0)
+    (2, 128, 128, 16, 64, 64, 1, 2), (2, 16, 0, 128, 64, 64, 1, 0), (2, 128, 0, 16, 32, 32, 0, 2), (1, 16, 0, 128, 32, 64, 0, 1),
+    (3, 40, 0, 9, 8, 32, 1, 0), (2, 9, 0, 70, 6, 32, 1, 1), (1, 64, 32, 12, 16, 128, 1, 1), (2, 16, 0, 16, 34, 32, 0, 0),
+    (1, 128, 0, 16, 128, 128, 1, 2), (5, 16, 0, 128, 64, 64, 1, 0), (2, 128, 0, 16, 20, 12, 1, 0), (1, 16, 0, 64, 84, 84, 1, 1)]
+
+
+@pytest.mark.parametrize("B,c1,c2,cout,H,W,pad,act", WTHIN)
+def test_thin_weight_gradient_vs_float64(K, B, c1, c2, cout, H, W, pad, act):
+    """Transition.conv6 / conv1, Encoder.conv4 shaped weight gradients (16 channels on one side): the Winograd form on
+    v_mfma_f32_16x16x4_f32 against float64 next to the direct kernel -- dw, db, per-sample channel sums; ungated, float
+    leaky-relu and sigmoid gates, both paddings, ragged channel counts, two input tensors, odd patch-row counts; twice,
+    bitwise equal (fixed summation order)."""
+    torch.manual_seed(4)
+    x1 = torch.randn(B, c1, H, W)
+    x2 = torch.randn(B, c2, H, W) if c2 else None
+    w = (torch.randn(cout, c1 + c2, 3, 3) * 0.05).double().requires_grad_(True)
+    bb = torch.randn(cout).double().requires_grad_(True)
+    xin = (x1 if x2 is None else torch.cat([x1, x2], 1)).double()
+    y = ref_conv(xin, w, bb, pad, act)
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    yf = y.detach().float().cuda()
+    sw, sb = max(1.0, float(w.grad.abs().max())), max(1.0, float(bb.grad.abs().max()))
+    e, first = {}, None
+    for wino in (1, 1, 0):
+        dw, db, csum = K.wgrad(wino, x1.cuda(), None if x2 is None else x2.cuda(), dy.float().cuda(), yf if act else None, act, pad)
+        if wino and first is None:
+            first = (dw.clone(), db.clone(), csum.clone())
+        elif wino:
+            assert torch.equal(dw, first[0]) and torch.equal(db, first[1]) and torch.equal(csum, first[2])
+        e[wino] = (float((dw.cpu().double() - w.grad).abs().max()) / sw, float((db.cpu().double() - bb.grad).abs().max()) / sb,
+                   float((csum.sum(0).cpu().double() - bb.grad).abs().max()) / sb)
+    assert max(e[1]) < 2e-6 and e[1][0] <= 3.0 * e[0][0] + 1e-8, e
+
+
 def test_bitwise_reproducible_and_layer_fallback():
     """Two launches give identical bits (fixed summation order, no atomics); a layer on a frame the kernels do not take
     (odd width) runs the direct kernels through the same autograd function and agrees with the direct algorithm bitwise."""

@@ -151,7 +151,7 @@ def timing():
             res[0], fl / res[0] / 1e6, res[1], fl / res[1] / 1e6, res[1] / res[0]))
 
 
-if __name__ == '__main__' and 'wgrad' not in sys.argv and 'w16' not in sys.argv:
+if __name__ == '__main__' and 'wgrad' not in sys.argv and 'w16' not in sys.argv and 'wg16' not in sys.argv:
     ok = check()
     if ok or 'time' in sys.argv:
         timing()
@@ -306,3 +306,61 @@ if __name__ == '__main__' and 'w16' in sys.argv:
     ok = check_w16()
     if ok or 'time' in sys.argv:
         timing_w16()
+
+
+# ---------------------------------------------------------------- weight gradient, 16-channel-side layers
+def check_wg16():
+    torch.manual_seed(3)
+    ok = True
+    for (B, c1, c2, cout, H, W, pad, act) in [
+            (2, 128, 128, 16, 64, 64, 1, 2), (2, 16, 0, 128, 64, 64, 1, 0), (2, 128, 0, 16, 32, 32, 0, 2),
+            (1, 16, 0, 128, 32, 64, 0, 1), (3, 40, 0, 9, 8, 32, 1, 0), (2, 9, 0, 70, 6, 32, 1, 1),
+            (1, 64, 32, 12, 16, 128, 1, 1), (2, 16, 0, 16, 34, 32, 0, 0), (1, 128, 0, 16, 128, 128, 1, 2),
+            (5, 16, 0, 128, 64, 64, 1, 0), (2, 128, 0, 16, 20, 12, 1, 0)]:
+        x1 = torch.randn(B, c1, H, W); x2 = torch.randn(B, c2, H, W) if c2 else None
+        w = (torch.randn(cout, c1 + c2, 3, 3) * 0.05).double().requires_grad_(True)
+        bb = torch.randn(cout).double().requires_grad_(True)
+        xin = (x1 if x2 is None else torch.cat([x1, x2], 1)).double()
+        y = ref_conv(xin, w, bb, pad, act)
+        dy = torch.randn_like(y)
+        y.backward(dy)
+        yf = y.detach().float().to(dev)
+        res = {}
+        for wino in (1, 0):
+            dw, db, csum = wgrad(wino, x1.to(dev), None if x2 is None else x2.to(dev), dy.float().to(dev), yf if act else None,
+                                 act, pad)
+            sc = max(1.0, w.grad.abs().max().item())
+            e1 = (dw.cpu().double() - w.grad).abs().max().item() / sc
+            e2 = (db.cpu().double() - bb.grad).abs().max().item() / max(1.0, bb.grad.abs().max().item())
+            e3 = (csum.sum(0).cpu().double() - bb.grad).abs().max().item() / max(1.0, bb.grad.abs().max().item())
+            res[wino] = (e1, e2, e3)
+        print('wg16', (B, c1, c2, cout, H, W, pad, act), ' '.join('%s dw %.1e db %.1e cs %.1e' % ('wino' if wn else 'direct', *res[wn]) for wn in res))
+        ok &= all(e < 1e-5 for e in res[1])
+    print('WG16 ALL OK' if ok else 'WG16 FAILED')
+    return ok
+
+
+def timing_wg16():
+    for (B, c1, c2, cout, H, W, act) in [(64, 128, 128, 16, 64, 64, 2), (64, 16, 0, 128, 64, 64, 0), (64, 128, 0, 16, 64, 64, 2),
+                                         (16, 128, 128, 16, 128, 128, 2), (8, 128, 128, 16, 64, 64, 2)]:
+        x1 = torch.randn(B, c1, H, W, device=dev); x2 = torch.randn(B, c2, H, W, device=dev) if c2 else None
+        dy = torch.randn(B, cout, H, W, device=dev); g = torch.rand(B, cout, H, W, device=dev) if act else None
+        res = []
+        for wino in (1, 0):
+            for _ in range(3): wgrad(wino, x1, x2, dy, g, act, 1)
+            torch.cuda.synchronize()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            n = 10
+            s.record()
+            for _ in range(n): wgrad(wino, x1, x2, dy, g, act, 1)
+            e.record(); torch.cuda.synchronize()
+            res.append(s.elapsed_time(e) / n * 1e3)
+        fl = 2.0 * B * H * W * cout * (c1 + c2) * 9
+        print('wg16 time', (B, c1, c2, cout, H, W), 'wino %.1f us (%.1f TF algorithmic)  direct %.1f us (%.1f TF)  x%.2f (incl. reduce)' % (
+            res[0], fl / res[0] / 1e6, res[1], fl / res[1] / 1e6, res[1] / res[0]))
+
+
+if __name__ == '__main__' and 'wg16' in sys.argv:
+    ok = check_wg16()
+    if ok or 'time' in sys.argv:
+        timing_wg16()

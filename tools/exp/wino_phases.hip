@@ -5,6 +5,8 @@
 #include "../../scm_gan_amd/csrc/conv3x3_wino.hip"
 #include "../../scm_gan_amd/csrc/conv3x3_wino16.hip"      // (the entry point dispatches the 16-channel form)
 #include <cstdio>
+#include <algorithm>
+#include <map>
 #include <vector>
 
 // the two helpers of api.cpp the kernel file needs (the harness does not link the library)
@@ -47,6 +49,27 @@ int main() {
             hipMemcpyFromSymbol(t, HIP_SYMBOL(wino_ticks), sizeof t);
             printf("cin %d: kernel %.1f us | ticks: prologue %llu  loop %llu (%llu per chunk)  epilogue %llu | total %llu\n", C,
                    ms * 1e3, t[0], t[1], t[1] / (C / 8), t[2], t[0] + t[1] + t[2]);
+            if (it == 2) {
+                // per-CU timeline: lifetime of a workgroup and the idle time between consecutive workgroups of one CU
+                static unsigned long long tr[3 * 8192];
+                hipMemcpyFromSymbol(tr, HIP_SYMBOL(wino_trace), sizeof tr);
+                const int nwg = CO / 128 * (B * (H / 2) * (W / 2) / 32) < 8192 ? CO / 128 * (B * (H / 2) * (W / 2) / 32) : 8192;
+                std::map<unsigned long long, std::vector<std::pair<unsigned long long, unsigned long long>>> cu;
+                for (int i = 0; i < nwg; ++i)
+                    cu[((tr[3 * i] >> 32) & 15) << 16 | (tr[3 * i] & 0xff00)].push_back({tr[3 * i + 1], tr[3 * i + 2]});
+                double life = 0, gap = 0; size_t nl = 0, ng = 0; unsigned long long span = 0;
+                for (auto& kv : cu) {
+                    auto& v = kv.second;
+                    std::sort(v.begin(), v.end());
+                    for (size_t i = 0; i < v.size(); ++i) {
+                        life += v[i].second - v[i].first; ++nl;
+                        if (i) { gap += (double)v[i].first - (double)v[i - 1].second; ++ng; }
+                    }
+                    span = std::max(span, v.back().second - v.front().first);
+                }
+                printf("  %zu CUs, %zu workgroups: mean lifetime %.0f ticks, mean gap to the next workgroup of the CU %.0f ticks, "
+                       "longest CU span %llu ticks\n", cu.size(), nl, life / nl, ng ? gap / ng : 0.0, span);
+            }
         }
         hipFree(x); hipFree(y); hipFree(w); hipFree(bias); hipFree(pack);
     }
