@@ -27,6 +27,10 @@
 
 typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
 
+__device__ __forceinline__ void wino16_mfma(f32x4& acc, float a, float b) {
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+
 template <int NJ, int PADC>
 __global__ void __launch_bounds__(256, 1) conv3x3_wino16_kernel(const ConvKArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -197,18 +201,24 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino16_kernel(const ConvKArgs 
     auto pair = [&](int chunk, auto set_, auto p_) {
         constexpr int SET = decltype(set_)::value, P = decltype(p_)::value;
         const int stn = (chunk + 1) & 1;
+        // acc += A x B with the accumulator TIED to its AGPRs: hipcc leaves the destination of this 4-register MFMA untied
+        // (unlike the 16-register ones) and its register allocator then permutes the accumulator tiles through
+        // v_accvgpr_read / _mov / _write every chunk (40-64 of each per 128 MFMAs).  As inline asm the compiler no longer
+        // sees an MFMA: the two hazards it would have padded are kept apart by construction -- a B operand is written
+        // (xf_math, set SET ^ 1) a whole chunk before it is read, and the two products into one accumulator are three
+        // MFMAs apart.
         auto mf = [&](auto f_, auto ks_, auto bk_) {
             constexpr int F = decltype(f_)::value, KS = decltype(ks_)::value, BK = decltype(bk_)::value;
-            acc[F][BK] = __builtin_amdgcn_mfma_f32_16x16x4f32(ur[P & 3][2 * (F & 1) + KS], bv[SET][2 * KS + BK][F], acc[F][BK], 0, 0, 0);
+            wino16_mfma(acc[F][BK], ur[P & 3][2 * (F & 1) + KS], bv[SET][2 * KS + BK][F]);
         };
         mf(IC(2 * P), IC(0), IC(0)); mf(IC(2 * P), IC(0), IC(1));
         if constexpr (P < 4) { x_store(stn, IC(P < 4 ? 2 * P : 0)); x_store(stn, IC(P < 4 ? 2 * P + 1 : 0)); }
         if constexpr (P >= 4) xf_rd(stn, IC((P - 4) >> 1), IC((P - 4) & 1));
         SB();
-        mf(IC(2 * P), IC(1), IC(0)); mf(IC(2 * P), IC(1), IC(1));
+        mf(IC(2 * P + 1), IC(0), IC(0)); mf(IC(2 * P + 1), IC(0), IC(1));
         if constexpr (P < 4) { x_load(chunk + 2, IC(P < 4 ? 2 * P : 0)); x_load(chunk + 2, IC(P < 4 ? 2 * P + 1 : 0)); }
         SB();
-        mf(IC(2 * P + 1), IC(0), IC(0)); mf(IC(2 * P + 1), IC(0), IC(1));
+        mf(IC(2 * P), IC(1), IC(0)); mf(IC(2 * P), IC(1), IC(1));
         if constexpr (P >= 4) xf_math(IC(SET ^ 1), IC((P - 4) >> 1), IC((P - 4) & 1));
         SB();
         mf(IC(2 * P + 1), IC(1), IC(0)); mf(IC(2 * P + 1), IC(1), IC(1));
@@ -241,10 +251,17 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino16_kernel(const ConvKArgs 
     xform(0, IC(0), IC(0), IC(0)); xform(0, IC(0), IC(0), IC(1)); xform(0, IC(0), IC(1), IC(0)); xform(0, IC(0), IC(1), IC(1));
     // (whole pairs of chunks: the accumulators must not cross a conditional.  A chunk past the end multiplies the
     // pack's zero slab by patches of the clamped last raw chunk.)
+    SB();
+    asm volatile("s_nop 1");          // (set 0 was written by the VALU just above: two wait states before an MFMA reads it)
+    SB();
     for (int chunk = 0; chunk < nchunk; chunk += 2) {
         chunk_body(chunk, IC(0));
         chunk_body(chunk + 1, IC(1));
     }
+    // (the wait states between the last MFMAs and the first read of a result, which the compiler cannot count any more)
+    SB();
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    SB();
 #undef IC
 #undef SB
 
