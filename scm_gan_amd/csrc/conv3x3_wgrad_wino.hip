@@ -56,14 +56,15 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wgrad_wino_kernel(const WgradK
     const int TCW = W >> 1, TRH = (H + 1) >> 1;
     const int nchr = (TCW + 7) >> 3;             // chunks per patch row
 
-    const int split = blockIdx.x;
+    int split, grp;
+    scm_xcd_split_group(split, grp);
     const int b = split / a.spi;
     const int si = split - b * a.spi;
     const int tr0 = si * a.rows_per_split;       // (rows_per_split counts PATCH rows here)
     int tr1 = tr0 + a.rows_per_split;
     if (tr1 > TRH) tr1 = TRH;
     const int nchunk = (tr1 > tr0 ? tr1 - tr0 : 0) * nchr;
-    const int cog = blockIdx.y / a.ci_groups, cig = blockIdx.y - cog * a.ci_groups;
+    const int cog = grp / a.ci_groups, cig = grp - cog * a.ci_groups;
     const int cin = a.c1 + a.c2;
     const int co = cog * 64 + ch, ci = cig * 64 + ch;
     const int coc = co < a.cout ? co : a.cout - 1, cic = ci < cin ? ci : cin - 1;
@@ -423,7 +424,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wgrad_wino_kernel(const WgradK
 #ifdef WW_TIMING
     __builtin_amdgcn_s_waitcnt(0);
     WW_TICK(2);
-    if (blockIdx.x == WW_TIMING && blockIdx.y == 0 && tid == 0)
+    if (split == WW_TIMING && grp == 0 && tid == 0)
         for (int i = 0; i < 4; ++i) ww_ticks[i] = t_acc[i];
 #endif
 }

@@ -68,7 +68,8 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wgrad_wino16_kernel(const Wgra
     const int TRH = H >> 1, TCW = W >> 1;
     const int xparts = W >> 5;
 
-    const int split = blockIdx.x;
+    int split, wg;                                   // wg: 32-channel group of the wide side
+    scm_xcd_split_group(split, wg);
     const int b = split / a.spi;
     const int si = split - b * a.spi;
     const int band = si / xparts, xpart = si - band * xparts;
@@ -76,7 +77,6 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wgrad_wino16_kernel(const Wgra
     int tr1 = tr0 + a.rows_per_split;
     if (tr1 > TRH) tr1 = TRH;
     const int nst = tr1 > tr0 ? tr1 - tr0 : 0;
-    const int wg = blockIdx.y;                       // 32-channel group of the wide side
     const int cin = a.c1 + a.c2;
 
     const int pl = wave * 4 + p;                     // this lane's patch column within the workgroup's 32 columns

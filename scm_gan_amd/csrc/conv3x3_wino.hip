@@ -82,9 +82,8 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_kernel(const ConvKArgs a)
     const int ROWPL = W + 6;                          // raw row: image column ix sits at ix + 3 (ix = -2 .. W+1; slot 0 unused):
                                                       // global pairs stay 8-byte aligned, patch reads (from ix = 2*tx-1) too
 
-    const int b = blockIdx.x / a.tiles_per_img;
-    const int wt = blockIdx.x - b * a.tiles_per_img;
-    const int cg = blockIdx.y;
+    int b, wt, cg;
+    scm_xcd_tile_map(a.B, a.tiles_per_img, b, wt, cg);
     const int t0 = wt * TW;
     const int ty0 = t0 / TCW;
     int tlast = t0 + TW - 1;
@@ -612,7 +611,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_kernel(const ConvKArgs a)
 #ifdef WINO_TIMING
     __builtin_amdgcn_s_waitcnt(0);
     WINO_TICK(2);
-    if (blockIdx.x == WINO_TIMING && blockIdx.y == 0 && tid == 0)
+    if (b * a.tiles_per_img + wt == WINO_TIMING && cg == 0 && tid == 0)
         for (int i = 0; i < 4; ++i) wino_ticks[i] = t_acc[i];
     __syncthreads();
     const unsigned wg_ = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;

@@ -49,8 +49,8 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino16_kernel(const ConvKArgs 
     const int ROWPL = W + 6;                          // raw row: image column ix at ix + 3 (conv3x3_wino.hip)
     const int HPR = (W + 4) >> 1;
 
-    const int b = blockIdx.x / a.tiles_per_img;
-    const int wt = blockIdx.x - b * a.tiles_per_img;
+    int b, wt, cg_;
+    scm_xcd_tile_map(a.B, a.tiles_per_img, b, wt, cg_);
     const int t0 = wt * W16_TILES;
     const int ty0 = t0 / TCW;
     int tlast = t0 + W16_TILES - 1;

@@ -29,3 +29,23 @@ int scm_pack_wino16(const float* w, int cin, int cout, int transposed_src, int w
                     float* dgrad_pack, hipStream_t s);
 bool scm_wino16_serves(int H, int W);
 int scm_launch_wino16(const ConvKArgs& k, hipStream_t s);
+
+// Workgroup -> (image, tile, output-channel group) for grids of (B * tiles_per_img, groups): neighbouring tiles of ONE
+// image (they share halo rows) and the channel groups of a tile (they read the same rows) run on ONE XCD, next to each
+// other in time -- each XCD has its own L2 and the hardware deals consecutive workgroup ids (x fastest) round robin over
+// the 8 XCDs, so with the plain mapping every shared row is fetched from HBM once per XCD that touches it.
+__device__ __forceinline__ void scm_xcd_tile_map(int B, int tiles_per_img, int& b, int& wt, int& cg) {
+    const int groups = gridDim.y;
+    if ((B & 7) == 0) {
+        const int id = blockIdx.y * gridDim.x + blockIdx.x;
+        const int q = id >> 3;
+        cg = q % groups;
+        const int r = q / groups;
+        wt = r % tiles_per_img;
+        b = (r / tiles_per_img) * 8 + (id & 7);
+    } else {
+        b = blockIdx.x / tiles_per_img;
+        wt = blockIdx.x - b * tiles_per_img;
+        cg = blockIdx.y;
+    }
+}

@@ -1,4 +1,5 @@
-"""128->128, B=64, 64x64 launches of the hot kernels as the training step issues them (1-bit gate mask on):
+"""128->128, B=64, 64x64 launches of the hot kernels as the training step issues them (1-bit gate mask on; since round 3
+also the producer-gated forms and the 16-channel-side layers of the transition):
 fp32 forward / gated dgrad / wgrad in the default Winograd form and in the direct form, their fp32-on-the-bf16-pipe (fp32x3)
 and 16-bit-operand forms, on preallocated buffers (for rocprofv3 --pmc passes)."""
 import ctypes, sys, torch
@@ -21,6 +22,11 @@ for mode in ('fp32', 'fp32-direct', 'fp32x3', 'fp16'):
     fp, dp, fprec, dprec = ops.pack_conv3x3(w, C, C)[:4]
     mask = torch.zeros(B, C // 32, H, W, device='cuda', dtype=torch.int32)
     for _ in range(3):
+        if mode == 'fp32':
+            # the product's form since round 3 (producer-side gating): the input gradient runs ungated and gates what it
+            # WRITES with the destination's mask -- the same instantiation as the forward, so it goes first and the forward's
+            # dispatch is the one the parser keeps; the weight gradient then runs ungated too (below)
+            ops._conv3x3_raw(gy, None, None, None, 0, dp, C, None, None, None, C, 1, ops.ACT_NONE, dprec, ymask1=mask)
         y, _ = ops._conv3x3_raw(x, None, None, None, 0, fp, C, None, bias, None, C, 1, ops.ACT_LRELU, fprec, mask_out=mask)
         dx, _ = ops._conv3x3_raw(gy, None, y, None, ops.ACT_LRELU, dp, C, None, None, None, C, 1, ops.ACT_NONE, dprec, mask_in=mask)
         d = L.WgradDesc(P(x), None, C, 0, P(gy), P(y), ops.ACT_LRELU, C, P(dw), P(db), None, P(part), P(cws), B, H, W, 1, 0, 0, 0, 0,
@@ -31,7 +37,32 @@ for mode in ('fp32', 'fp32-direct', 'fp32x3', 'fp16'):
             L.check(lib.scm_conv3x3_wgrad_h16(ctypes.byref(d), dprec, S()), 'wgrad_h16')
         else:
             L.check(lib.scm_conv3x3_wgrad(ctypes.byref(d), S()), 'wgrad')
+        if mode == 'fp32':
+            d0 = L.WgradDesc(P(x), None, C, 0, P(gy), None, 0, C, P(dw), P(db), None, P(part), P(cws), B, H, W, 1, 0, 0, 0, 0,
+                             None, None, None)
+            L.check(lib.scm_conv3x3_wgrad_wino(ctypes.byref(d0), S()), 'wgrad_wino ungated')
     torch.cuda.synchronize()
+# the 16-channel-side layers of the transition (fp32, Winograd forms): conv6's forward (256 -> 16, sigmoid) and weight
+# gradient (sigmoid gate), conv1's weight gradient (16 -> 128, ungated)
+ops.set_compute_precision('fp32')
+ops.set_conv_algo('winograd')
+xa, xb_ = torch.randn(B, C, H, W, device='cuda'), torch.randn(B, C, H, W, device='cuda')
+w6 = torch.randn(16, 2 * C, 3, 3, device='cuda') * 0.05
+z16 = torch.randn(B, 16, H, W, device='cuda'); g16 = torch.randn(B, 16, H, W, device='cuda') * 1e-4
+fp6 = ops.pack_conv3x3(w6, 2 * C, 16)
+pf6, cf6 = ctypes.c_size_t(), ctypes.c_size_t()
+lib.scm_conv3x3_wgrad_workspace(B, H, W, 2 * C, 16, ctypes.byref(pf6), ctypes.byref(cf6))
+part6 = torch.empty(max(pf6.value, pf.value), device='cuda'); cws6 = torch.empty(max(cf6.value, cf.value), device='cuda')
+dw6 = torch.empty_like(w6); db6 = torch.empty(16, device='cuda'); dw1 = torch.empty(C, 16, 3, 3, device='cuda'); db1 = torch.empty(C, device='cuda')
+for _ in range(3):
+    p6, _ = ops._conv3x3_raw(xa, xb_, None, None, 0, fp6[0], 16, None, torch.zeros(16, device='cuda'), None, 16, 1, ops.ACT_SIGMOID, fp6[2])
+    d6 = L.WgradDesc(P(xa), P(xb_), C, C, P(g16), P(p6), ops.ACT_SIGMOID, 16, P(dw6), P(db6), None, P(part6), P(cws6), B, H, W, 1,
+                     0, 0, 0, 0, None, None, None)
+    L.check(lib.scm_conv3x3_wgrad_wino(ctypes.byref(d6), S()), 'wgrad_wino conv6')
+    d1 = L.WgradDesc(P(z16), None, 16, 0, P(gy), None, 0, C, P(dw1), P(db1), None, P(part6), P(cws6), B, H, W, 1, 0, 0, 0, 0,
+                     None, None, None)
+    L.check(lib.scm_conv3x3_wgrad_wino(ctypes.byref(d1), S()), 'wgrad_wino conv1')
+torch.cuda.synchronize()
 # the fused decoder + BCE launches of one unrolled step (fp32): forward, backward, at the bench batch
 ops.set_compute_precision('fp32')
 ops.set_conv_algo('winograd')
