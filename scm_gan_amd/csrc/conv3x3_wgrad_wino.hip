@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wgrad_wino_kernel(const WgradK
     const int nchr = (TCW + 7) >> 3;             // chunks per patch row
 
     int split, grp;
-    scm_xcd_split_group(split, grp);
+    scm_xcd_split_group(a.spi, split, grp);
     const int b = split / a.spi;
     const int si = split - b * a.spi;
     const int tr0 = si * a.rows_per_split;       // (rows_per_split counts PATCH rows here)

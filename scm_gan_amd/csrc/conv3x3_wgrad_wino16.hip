@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wgrad_wino16_kernel(const Wgra
     const int xparts = W >> 5;
 
     int split, wg;                                   // wg: 32-channel group of the wide side
-    scm_xcd_split_group(split, wg);
+    scm_xcd_split_group(a.spi, split, wg);
     const int b = split / a.spi;
     const int si = split - b * a.spi;
     const int band = si / xparts, xpart = si - band * xparts;

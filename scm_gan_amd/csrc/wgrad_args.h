@@ -13,17 +13,19 @@ struct WgradKArgs {
     const unsigned* gate_mask;     // 1-bit leaky-relu gate, words [B][ceil(cout/32)][HW], or null
 };
 
-// Workgroup -> (split, channel group) for grids of (splits, groups): the groups of one split read the same rows, so they
-// run on ONE XCD (own L2), next to each other in time.  The hardware deals consecutive workgroup ids (x fastest) round
-// robin over the 8 XCDs; with the plain mapping the groups of a split start a whole grid row apart and each of them
-// fetches its rows from HBM again (PMC: 718 MB per conv6 weight gradient, 4.7 TB/s, against 290 MB of distinct bytes).
-__device__ __forceinline__ void scm_xcd_split_group(int& split, int& group) {
+// Workgroup -> (split, channel group) for grids of (B * spi splits, groups): the groups of one split read the same rows
+// and the splits of one image share border rows / columns, so one IMAGE runs on ONE XCD (own L2), its workgroups next
+// to each other in time.  The hardware deals consecutive workgroup ids (x fastest) round robin over the 8 XCDs; with
+// the plain mapping the groups of a split start a whole grid row apart and each of them fetches its rows from HBM
+// again (PMC: 718 MB per conv6 weight gradient, 4.7 TB/s, against 290 MB of distinct bytes).
+__device__ __forceinline__ void scm_xcd_split_group(int spi, int& split, int& group) {
     const int nsplit = gridDim.x, groups = gridDim.y;
     const int id = blockIdx.y * nsplit + blockIdx.x;
-    if ((nsplit & 7) == 0) {
+    if ((nsplit & 7) == 0 && ((nsplit / spi) & 7) == 0) {
         const int q = id >> 3;
-        split = (q / groups) * 8 + (id & 7);
-        group = q - (q / groups) * groups;
+        group = q % groups;
+        const int r = q / groups;
+        split = ((r / spi) * 8 + (id & 7)) * spi + r % spi;
     } else {
         split = blockIdx.x;
         group = blockIdx.y;
