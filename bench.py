@@ -375,12 +375,13 @@ def main():
     for i in range(a.warmup):
         trainer.step(*batches[i % 2], theta=0.5, train_iter=i + 1)
     # HIP-event brackets around the MFMA conv launches (roofline): recorded on the launch stream inside the timed
-    # region, on every 5th step only -- two events per launch on all ~3000 launches cost 1.5 % of the step
+    # region, on every 10th step only -- two events per launch stall the queue between kernels: on all steps they cost
+    # ~8 % of the step, on every 5th 1.8 %, on every 10th 0.9 %
     timer = ops.KernelTimer() if (not a.no_kernel_timer and rank == 0) else None
     barrier()
     t0 = time.perf_counter()
     for i in range(a.steps):
-        ops.kernel_timer = timer if i % 5 == 0 else None
+        ops.kernel_timer = timer if i % 10 == 0 else None
         trainer.step(*batches[i % 2], theta=0.5, train_iter=a.warmup + i + 1)
     barrier()
     dt = time.perf_counter() - t0
@@ -445,8 +446,8 @@ def main():
                                "unit": "TFLOP/s", "frac": achieved / peak,
                                "traffic": tr_info["bytes"] if tr_info else None, "traffic_source": tr_info,
                                "launches": s["launches"], "avg_launch_us": s["ms"] * 1e3 / s["launches"],
-                               # brackets are recorded on every 5th timed step: scale to the whole timed region
-                               "share_of_step": s["ms"] / (dt * 1e3) * a.steps / len(range(0, a.steps, 5))}
+                               # brackets are recorded on every 10th timed step: scale to the whole timed region
+                               "share_of_step": s["ms"] / (dt * 1e3) * a.steps / len(range(0, a.steps, 10))}
             if wino:
                 # `achieved` counts the ALGORITHMIC FLOPs of the convolution (2 * 9 MACs per output and input channel);
                 # Winograd F(2x2,3x3) issues 4/9 of them on the f32 MFMA pipe, so `frac` can exceed 1 -- the share of

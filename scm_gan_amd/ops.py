@@ -226,7 +226,9 @@ kernel_timer = None     # set to a KernelTimer() to time the MFMA conv launches
 
 def conv_kernel_name(cout, prec=0):
     if prec == ALGO_WINO:
-        return "conv3x3_wino_kernel"
+        # (the entry point sends layers with at most 16 output channels to the 16-row kernel: its own bucket, so that the
+        # bracketed average of the wide kernel is that kernel's and agrees with rocprofv3's)
+        return "conv3x3_wino16_kernel" if cout <= 16 else "conv3x3_wino_kernel"
     if prec == PREC_BF16X3:
         return "conv3x3_x3_kernel"
     if prec:
