@@ -310,6 +310,8 @@ def test_producer_side_gating_equals_consumer_side():
     (a two-consumer sum is gated per contribution instead of once)."""
     import weights as WS
     from scm_gan_amd import models as M, ops
+    if ops.conv_algo() != "winograd" or ops.compute_precision() != "fp32":
+        pytest.skip("producer-side gating belongs to the Winograd kernels (SCM_CONV_ALGO / SCM_PRECISION select another path)")
     torch.manual_seed(0)
     res = {}
     for pre in (True, False):
