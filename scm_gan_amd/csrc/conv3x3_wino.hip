@@ -675,10 +675,16 @@ __global__ void pack_conv3x3_wino_kernel(const float* __restrict__ w, int cin, i
 }
 
 // ------------------------------------------------------------------ host
+static inline size_t wino_wide_pack_floats(int cin, int cout) {
+    return (size_t)((cout + WINO_CO - 1) / WINO_CO) * ((cin + KC - 1) / KC) * WINO_SLAB;
+}
+
 extern "C" size_t scm_conv3x3_pack_wino_floats(int cin, int cout) {
     if (cin <= 0 || cout <= 0) return 0;
     if (cout <= 16) return scm_wino16_pack_floats(cin);          // the 16-row kernel's layout (conv3x3_wino16.hip)
-    return (size_t)((cout + WINO_CO - 1) / WINO_CO) * ((cin + KC - 1) / KC) * WINO_SLAB;
+    // (<= 16 input channels: the pack of conv3x3_wino_k16.hip follows the wide kernel's -- which kernel runs is
+    // decided per launch, scm_wino_k16_serves)
+    return wino_wide_pack_floats(cin, cout) + (cin <= 16 ? scm_wino_k16_pack_floats(cout) : 0);
 }
 
 extern "C" int scm_pack_conv3x3_weights_wino(const float* w, int cin, int cout, int transposed_src, int w_cin_total,
@@ -696,10 +702,17 @@ extern "C" int scm_pack_conv3x3_weights_wino(const float* w, int cin, int cout, 
         if (d16) dgrad_pack = nullptr;
         if (!fwd_pack && !dgrad_pack) return SCM_OK;
     }
+    // a direction with <= 16 input channels gets the thin-input kernel's pack behind the wide one
+    {
+        float* fk = (fwd_pack && cin <= 16) ? fwd_pack + wino_wide_pack_floats(cin, cout) : nullptr;
+        float* dk = (dgrad_pack && cout <= 16) ? dgrad_pack + wino_wide_pack_floats(cout, cin) : nullptr;
+        if (fk || dk)
+            if (int rc = scm_pack_wino_k16(w, cin, cout, transposed_src, w_cin_total, w_ci0, fk, dk, (hipStream_t)stream)) return rc;
+    }
     size_t n = 0;
-    if (fwd_pack) n = scm_conv3x3_pack_wino_floats(cin, cout) / 16;
+    if (fwd_pack) n = wino_wide_pack_floats(cin, cout) / 16;
     if (dgrad_pack) {
-        const size_t m = scm_conv3x3_pack_wino_floats(cout, cin) / 16;
+        const size_t m = wino_wide_pack_floats(cout, cin) / 16;
         if (m > n) n = m;
     }
     const int threads = 256;
@@ -795,6 +808,12 @@ extern "C" int scm_conv3x3_wino(const scm_conv3x3_desc* d, void* stream) {
                   reinterpret_cast<size_t>(d->y1) | reinterpret_cast<size_t>(d->y2) |
                   reinterpret_cast<size_t>(d->gate_mask_out)) & 7) == 0,
                 "scm_conv3x3_wino: tensors must be 8-byte aligned");
+    if (d->c1 + d->c2 <= 16 && scm_wino_k16_serves(k)) {
+        // at most 16 input channels: the kernel that walks the output channels (conv3x3_wino_k16.hip); its pack lies behind
+        // the wide kernel's in the same buffer
+        k.wpack = d->wpack + wino_wide_pack_floats(d->c1 + d->c2, d->cout);
+        return scm_launch_wino_k16(k, (hipStream_t)stream);
+    }
     const int ntiles = ((d->H + 1) / 2) * (d->W / 2);
     // 128 output channels per workgroup (half the transform and staging work per MFMA) where the layer has whole
     // 128-channel groups, one output tensor per group and the patch rows tile 32 patches

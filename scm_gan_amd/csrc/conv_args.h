@@ -30,6 +30,13 @@ int scm_pack_wino16(const float* w, int cin, int cout, int transposed_src, int w
 bool scm_wino16_serves(int H, int W);
 int scm_launch_wino16(const ConvKArgs& k, hipStream_t s);
 
+// <= 16 INPUT channels, many output channels (conv3x3_wino_k16.hip): its pack follows the wide kernel's in the same buffer
+size_t scm_wino_k16_pack_floats(int n_out);
+int scm_pack_wino_k16(const float* w, int cin, int cout, int transposed_src, int w_cin_total, int w_ci0, float* fwd_pack,
+                      float* dgrad_pack, hipStream_t s);
+bool scm_wino_k16_serves(const ConvKArgs& a);
+int scm_launch_wino_k16(const ConvKArgs& k, hipStream_t s);
+
 // Workgroup -> (image, tile, output-channel group) for grids of (B * tiles_per_img, groups): neighbouring tiles of ONE
 // image (they share halo rows) and the channel groups of a tile (they read the same rows) run on ONE XCD, next to each
 // other in time -- each XCD has its own L2 and the hardware deals consecutive workgroup ids (x fastest) round robin over

@@ -196,6 +196,47 @@ def test_weight_gradient_vs_float64(K, B, c1, c2, cout, H, W, pad, act):
         assert max(e[1]) < 2e-6 and e[1][0] <= 3.0 * e[0][0] + 1e-8, (mode, e)
 
 
+KTHIN = [  # B, cin <= 16, cout, H, W, circular, act, gate_act (input gradient form), co1 (split), accumulate
+    (2, 16, 128, 16, 16, 1, 1, 0, None, False), (2, 16, 256, 64, 64, 1, 0, 2, 128, False), (1, 9, 72, 20, 12, 0, 1, 0, None, False),
+    (3, 12, 100, 9, 8, 1, 0, 1, 64, True), (1, 16, 64, 33, 22, 0, 1, 0, None, False), (2, 16, 48, 6, 6, 1, 0, 2, 16, False),
+    (1, 16, 128, 128, 128, 1, 1, 0, None, False)]
+
+
+@pytest.mark.parametrize("B,cin,cout,H,W,pad,act,gact,co1,acc", KTHIN)
+def test_sixteen_input_channel_form_vs_float64(K, B, cin, cout, H, W, pad, act, gact, co1, acc):
+    """conv3x3_wino_k16.hip (Transition.conv1's forward, conv6's input gradient): scale, bias, per-sample bias, leaky-relu
+    + the 1-bit gate words it writes, float-gated inputs (leaky-relu / sigmoid), split and accumulated outputs, ragged
+    channel counts, odd heights, both paddings -- against float64 next to the wide Winograd kernel (SCM_NO_WINO_K16 is read
+    once per process, so the comparison partner here is the direct kernel)."""
+    torch.manual_seed(6)
+    x = torch.randn(B, cin, H, W)
+    w, b, sb, sc = torch.randn(cout, cin, 3, 3) * 0.05, torch.randn(cout), torch.randn(B, cout) * 0.3, torch.tensor([0.8])
+    gate = torch.rand(B, cin, H, W) - (0.5 if gact == 1 else 0.0) if gact else None
+    xin = x.double()
+    if gact == 1:
+        xin = xin * torch.where(gate > 0, 1.0, 0.01).double()
+    if gact == 2:
+        xin = xin * (gate * (1 - gate)).double()
+    yr = ref_conv(xin, w.double() * 0.8, None, pad, 0) + (b.double()[None, :, None, None] + sb.double()[:, :, None, None])
+    yr = F.leaky_relu(yr) if act == 1 else yr
+    base = torch.randn(B, co1 or cout, H, W) if acc else None
+    err, masks = {}, {}
+    for wino in (1, 0):
+        fp, _ = K.pack(w.cuda(), wino)
+        mo = torch.zeros(B, (cout + 31) // 32, H, W, device="cuda", dtype=torch.int32) if (act == 1 and cout > 32) else None
+        y1, y2 = K.conv(wino, x.cuda(), None, fp, cout, pad, act, bias=b.cuda(), sbias=sb.cuda(), scale=sc.cuda(),
+                        gate1=None if gate is None else gate.cuda(), gate_act=gact, co1=co1, mask_out=mo,
+                        y1_acc=None if base is None else base.cuda().clone())
+        y = y1 if y2 is None else torch.cat([y1, y2], 1)
+        ref = yr.clone()
+        if acc:
+            ref[:, :base.shape[1]] += base.double()
+        err[wino] = float((y.cpu().double() - ref).abs().max())
+        if mo is not None:
+            assert torch.equal(mo, mask_words(y))
+    assert err[1] < 2e-5 and err[1] <= 2.0 * err[0] + 1e-6, err
+
+
 WTHIN = [  # B, c1, c2, cout, H, W, circular, act: at most 16 channels on one side (conv3x3_wgrad_wino16.hip), and shapes
     # it hands to the direct kernel (W % 32 != 0)
     (2, 128, 128, 16, 64, 64, 1, 2), (2, 16, 0, 128, 64, 64, 1, 0), (2, 128, 0, 16, 32, 32, 0, 2), (1, 16, 0, 128, 32, 64, 0, 1),
