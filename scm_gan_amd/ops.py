@@ -224,11 +224,13 @@ class KernelTimer(object):
 kernel_timer = None     # set to a KernelTimer() to time the MFMA conv launches
 
 
-def conv_kernel_name(cout, prec=0):
+def conv_kernel_name(cout, prec=0, cin=None):
     if prec == ALGO_WINO:
-        # (the entry point sends layers with at most 16 output channels to the 16-row kernel: its own bucket, so that the
-        # bracketed average of the wide kernel is that kernel's and agrees with rocprofv3's)
-        return "conv3x3_wino16_kernel" if cout <= 16 else "conv3x3_wino_kernel"
+        # (the entry point sends layers with at most 16 output / input channels to the 16-row / 16-input-channel kernels:
+        # their own buckets, so that the bracketed average of the wide kernel is that kernel's and agrees with rocprofv3's)
+        if cout <= 16:
+            return "conv3x3_wino16_kernel"
+        return "conv3x3_wino_k16_kernel" if (cin is not None and cin <= 16) else "conv3x3_wino_kernel"
     if prec == PREC_BF16X3:
         return "conv3x3_x3_kernel"
     if prec:
@@ -258,7 +260,7 @@ def _conv3x3_raw(x1, x2, gate1, gate2, gate_act, wpack, cout, scale, bias, sbias
                    _p(sbias), _p(y1), _p(y2), co1, B, H, W, pad, act, _p(mask_out), _p(mask_in),
                    0 if y1_acc is None else 1, _p(ymask1), _p(ymask2))
     if kernel_timer is not None:
-        ev = kernel_timer.bracket(conv_kernel_name(cout, prec), 2.0 * B * H * W * cout * (c1 + c2) * 9)
+        ev = kernel_timer.bracket(conv_kernel_name(cout, prec, c1 + c2), 2.0 * B * H * W * cout * (c1 + c2) * 9)
         ev[0].record()
     if prec == ALGO_WINO:
         L.check(lib.scm_conv3x3_wino(ctypes.byref(d), _stream()), "scm_conv3x3_wino")
