@@ -50,6 +50,7 @@ xa, xb_ = torch.randn(B, C, H, W, device='cuda'), torch.randn(B, C, H, W, device
 w6 = torch.randn(16, 2 * C, 3, 3, device='cuda') * 0.05
 z16 = torch.randn(B, 16, H, W, device='cuda'); g16 = torch.randn(B, 16, H, W, device='cuda') * 1e-4
 fp6 = ops.pack_conv3x3(w6, 2 * C, 16)
+fp1 = ops.pack_conv3x3(torch.randn(C, 16, 3, 3, device='cuda') * 0.05, 16, C)
 pf6, cf6 = ctypes.c_size_t(), ctypes.c_size_t()
 lib.scm_conv3x3_wgrad_workspace(B, H, W, 2 * C, 16, ctypes.byref(pf6), ctypes.byref(cf6))
 part6 = torch.empty(max(pf6.value, pf.value), device='cuda'); cws6 = torch.empty(max(cf6.value, cf.value), device='cuda')
@@ -62,6 +63,11 @@ for _ in range(3):
     d1 = L.WgradDesc(P(z16), None, 16, 0, P(gy), None, 0, C, P(dw1), P(db1), None, P(part6), P(cws6), B, H, W, 1, 0, 0, 0, 0,
                      None, None, None)
     L.check(lib.scm_conv3x3_wgrad_wino(ctypes.byref(d1), S()), 'wgrad_wino conv1')
+    # conv6's input gradient (16 -> 256, sigmoid gate, both outputs gated by their activations' masks) and conv1's forward
+    # (16 -> 128, leaky-relu + gate words): the 16-input-channel kernel
+    ops._conv3x3_raw(g16, None, p6, None, ops.ACT_SIGMOID, fp6[1], 2 * C, None, None, None, C, 1, ops.ACT_NONE, fp6[3],
+                     ymask1=mask, ymask2=mask)
+    ops._conv3x3_raw(z16, None, None, None, 0, fp1[0], C, None, bias, None, C, 1, ops.ACT_LRELU, fp1[2], mask_out=mask)
 torch.cuda.synchronize()
 # the fused decoder + BCE launches of one unrolled step (fp32): forward, backward, at the bench batch
 ops.set_compute_precision('fp32')
