@@ -98,7 +98,7 @@ set_compute_precision(os.environ.get("SCM_PRECISION", "") or "fp32")
 # WINO_MIN_CH channels on either side, and frames scm_conv3x3_wino_serves() declines, run the direct kernels.
 _conv_algo = [os.environ.get("SCM_CONV_ALGO", "") or "winograd"]
 WINO_MIN_COUT = int(os.environ.get("SCM_WINO_MIN_COUT", "") or 64)
-WINO_MIN_CIN = int(os.environ.get("SCM_WINO_MIN_CIN", "") or 16)
+WINO_MIN_CIN = int(os.environ.get("SCM_WINO_MIN_CIN", "") or 8)
 
 
 def conv_algo():
