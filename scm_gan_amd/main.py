@@ -214,13 +214,22 @@ class Trainer(object):
         SN.clear_precomputed([encoder, transition, self.discriminator])
         main_stream = torch.cuda.current_stream()
         self.side_stream.wait_stream(main_stream)           # (the previous iteration's Adam)
-        with torch.cuda.stream(self.side_stream):           # ~1.3 ms on 5 CUs, needed only after the encoder (~1.5 ms)
-            SN.precompute([transition], prediction_horizon - 2)
+        # (two launches: the first transition call's iterations -- ~0.2 ms on 5 CUs, ready well before the encoder ends --
+        # and the remaining calls', which then have until the SECOND transition call; as one launch of 1.36 ms next to
+        # the 1.1 ms encoder the main stream waited 0.17 ms for it every iteration)
+        ncalls = prediction_horizon - 2
+        with torch.cuda.stream(self.side_stream):
+            first = ncalls if (ncalls <= 1 or os.environ.get("SCM_SN_ONE_LAUNCH", "0") not in ("", "0")) else 1
+            SN.precompute([transition], first)
+            self.sn_first = torch.cuda.Event()
+            self.sn_first.record(self.side_stream)
+            if ncalls > first:
+                SN.precompute([transition], ncalls - first)
         SN.precompute([encoder] + ([self.discriminator] if self.gan else []), 1)
 
         z = encoder(states[:, 0:3])                                            # main.py:162
         self.sync.arm(z)
-        main_stream.wait_stream(self.side_stream)
+        main_stream.wait_event(self.sn_first)
         targets = states.transpose(0, 1).contiguous()      # (T, B, C, H, W): targets[t] is one contiguous frame batch
         z_orig = z.clone() if (enable_cf_shuffle_loss or enable_control_bias_loss) else None
         active_mask = torch.ones(batch_size, device=states.device)
@@ -240,6 +249,8 @@ class Trainer(object):
             ts.collect('Rd Loss t={}'.format(t), reward_difference)
             ts.collect('Reconstruction t={}'.format(t), rec_loss)
 
+            if t == 2:
+                main_stream.wait_stream(self.side_stream)                      # (the remaining calls' power iterations)
             z = transition(z, onehots[:, t])                                   # main.py:206-215
 
             if a.latent_overshooting:
