@@ -131,6 +131,33 @@ def wino_serves(H, W):
 
 
 # ------------------------------------------------------------------ packs
+class PackSet(object):
+    """(forward pack, dgrad pack, forward algorithm, dgrad algorithm, native forward pack, native dgrad pack) of a layer in
+    the Winograd mode, indexable like the tuple it replaces.  The native packs of the directions the Winograd kernels
+    serve are only a per-launch fallback: they are built when first asked for (items 4 / 5)."""
+
+    def __init__(self, fpack, dpack, fprec, dprec, nfp, ndp, build):
+        self._items = [fpack, dpack, fprec, dprec, nfp, ndp]
+        self._build = build
+
+    def _get(self, i):
+        if i in (4, 5) and self._items[i] is None:
+            f, d = self._build(i == 4, i == 5)
+            self._items[i] = f if i == 4 else d
+        return self._items[i]
+
+    def __len__(self):
+        return 6
+
+    def __getitem__(self, key):
+        if isinstance(key, slice):
+            return tuple(self._get(i) for i in range(*key.indices(6)))
+        return self._get(key if key >= 0 else key + 6)
+
+    def __iter__(self):
+        return (self._get(i) for i in range(6))
+
+
 def pack_conv3x3(weight, cin, cout, transposed=False, cin_total=0, ci0=0):
     """Weight packs for scm_conv3x3 / scm_conv3x3_h16 from a torch-layout weight, in the
     current compute precision: (forward pack, dgrad pack, forward prec, dgrad prec)."""
@@ -142,10 +169,27 @@ def pack_conv3x3(weight, cin, cout, transposed=False, cin_total=0, ci0=0):
         L.check(lib.scm_pack_conv3x3_weights_h16(_p(w), cin, cout, int(transposed), cin_total, ci0, _p(fp), PREC_F16,
                                                  _p(dp), PREC_BF16, _stream()), "scm_pack_conv3x3_weights_h16")
         return fp, dp, PREC_F16, PREC_BF16
-    fp = _new(w, lib.scm_conv3x3_pack_floats(cin, cout))
-    dp = _new(w, lib.scm_conv3x3_pack_floats(cout, cin))
-    L.check(lib.scm_pack_conv3x3_weights(_p(w), cin, cout, int(transposed), cin_total, ci0, _p(fp), _p(dp), _stream()),
-            "scm_pack_conv3x3_weights")
+    def native(want_f, want_d):
+        f = _new(w, lib.scm_conv3x3_pack_floats(cin, cout)) if want_f else None
+        d = _new(w, lib.scm_conv3x3_pack_floats(cout, cin)) if want_d else None
+        L.check(lib.scm_pack_conv3x3_weights(_p(w), cin, cout, int(transposed), cin_total, ci0, _p(f), _p(d), _stream()),
+                "scm_pack_conv3x3_weights")
+        return f, d
+    if _precision[0] == "fp32" and _conv_algo[0] == "winograd":
+        # transformed-filter packs for the directions wide enough on both sides; the native packs of those directions are
+        # only the per-call fallback for frames / operand layouts the kernels do not take (wino_serves): built on first use
+        # (<= 16 output channels: the 16-row form, scm_conv3x3_wino16_serves; from 32 input channels on)
+        fwd_w = (cout >= WINO_MIN_COUT and cin >= WINO_MIN_CIN) or (cout <= 16 and cin >= 32 and WINO16)
+        dgr_w = (cin >= WINO_MIN_COUT and cout >= WINO_MIN_CIN) or (cin <= 16 and cout >= 32 and WINO16)
+        if fwd_w or dgr_w:
+            fx = _new(w, lib.scm_conv3x3_pack_wino_floats(cin, cout)) if fwd_w else None
+            dx = _new(w, lib.scm_conv3x3_pack_wino_floats(cout, cin)) if dgr_w else None
+            L.check(lib.scm_pack_conv3x3_weights_wino(_p(w), cin, cout, int(transposed), cin_total, ci0, _p(fx), _p(dx),
+                                                      _stream()), "scm_pack_conv3x3_weights_wino")
+            fp, dp = native(not fwd_w, not dgr_w) if not (fwd_w and dgr_w) else (None, None)
+            return PackSet(fx if fwd_w else fp, dx if dgr_w else dp, ALGO_WINO if fwd_w else PREC_F32,
+                           ALGO_WINO if dgr_w else PREC_F32, fp, dp, native)
+    fp, dp = native(True, True)
     if _precision[0] == "fp32x3":
         # split packs for the directions the x3 kernel serves (> 16 output channels); the native packs stay as the
         # per-call fallback for frames it does not take (x3_serves)
@@ -162,19 +206,6 @@ def pack_conv3x3(weight, cin, cout, transposed=False, cin_total=0, ci0=0):
                                                     _stream()), "scm_pack_conv3x3_weights_x3")
         return (fx if fx is not None else fp, dx if dx is not None else dp, PREC_BF16X3 if fx is not None else PREC_F32,
                 PREC_BF16X3 if dx is not None else PREC_F32, fp, dp)
-    if _conv_algo[0] == "winograd":
-        # transformed-filter packs for the directions wide enough on both sides; the native packs stay as the
-        # per-call fallback for frames the kernel does not take (wino_serves)
-        # (<= 16 output channels: the 16-row form, scm_conv3x3_wino16_serves; from 32 input channels on)
-        fwd_w = (cout >= WINO_MIN_COUT and cin >= WINO_MIN_CIN) or (cout <= 16 and cin >= 32 and WINO16)
-        dgr_w = (cin >= WINO_MIN_COUT and cout >= WINO_MIN_CIN) or (cin <= 16 and cout >= 32 and WINO16)
-        if fwd_w or dgr_w:
-            fx = _new(w, lib.scm_conv3x3_pack_wino_floats(cin, cout)) if fwd_w else None
-            dx = _new(w, lib.scm_conv3x3_pack_wino_floats(cout, cin)) if dgr_w else None
-            L.check(lib.scm_pack_conv3x3_weights_wino(_p(w), cin, cout, int(transposed), cin_total, ci0, _p(fx), _p(dx),
-                                                      _stream()), "scm_pack_conv3x3_weights_wino")
-            return (fx if fwd_w else fp, dx if dgr_w else dp, ALGO_WINO if fwd_w else PREC_F32,
-                    ALGO_WINO if dgr_w else PREC_F32, fp, dp)
     return fp, dp, PREC_F32, PREC_F32
 
 
