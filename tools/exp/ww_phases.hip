@@ -1,6 +1,6 @@
 // Where does a conv3x3_wgrad_wino workgroup spend its time?  Phase clock of wave 0 of one workgroup of the 128 -> 128,
 // 64 x 64 x 64 weight gradient (1-bit gate): ticks of prologue / K loop / epilogue.  -DWW_ABL=n removes work from the
-// loop (1: global loads, 2: + transforms, 3: + LDS writes, 4: + LDS operand reads).
+// loop (1: global loads, 2: + transforms, 3: + LDS writes, 4: + LDS operand reads); -DWW_UNGATED: no gate (the product's form).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DWW_TIMING=20 -I scm_gan_amd/csrc -I include tools/exp/ww_phases.hip \
 //         -o tools/exp/bin/ww_phases
 #include "../../scm_gan_amd/csrc/conv3x3_wgrad_wino.hip"
@@ -31,6 +31,9 @@ int main() {
     WgradKArgs a = {};
     a.x1 = x; a.c1 = C; a.dy = dy; a.gate = dy; a.gate_act = SCM_ACT_LRELU; a.cout = C; a.part = part; a.csum_part = cs;
     a.B = B; a.H = H; a.W = W; a.pad_mode = SCM_PAD_CIRCULAR; a.gate_mask = mask;
+#ifdef WW_UNGATED        // the form the product runs since the producers gate
+    a.gate = nullptr; a.gate_act = 0; a.gate_mask = nullptr;
+#endif
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     for (int it = 0; it < 3; ++it) {
