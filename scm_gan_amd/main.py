@@ -231,6 +231,7 @@ class Trainer(object):
         self.sync.arm(z)
         main_stream.wait_event(self.sn_first)
         targets = states.transpose(0, 1).contiguous()      # (T, B, C, H, W): targets[t] is one contiguous frame batch
+        onehots_t = onehots.transpose(0, 1).contiguous()   # (T, B, A): one copy instead of one per unrolled step
         z_orig = z.clone() if (enable_cf_shuffle_loss or enable_control_bias_loss) else None
         active_mask = torch.ones(batch_size, device=states.device)
 
@@ -251,7 +252,7 @@ class Trainer(object):
 
             if t == 2:
                 main_stream.wait_stream(self.side_stream)                      # (the remaining calls' power iterations)
-            z = transition(z, onehots[:, t])                                   # main.py:206-215
+            z = transition(z, onehots_t[t])                                    # main.py:206-215
 
             if a.latent_overshooting:
                 # main.py:217-230 (structure kept, incl. its index quirks)
