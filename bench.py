@@ -234,6 +234,24 @@ def decoder_leg(dev, batch):
     return out
 
 
+def git_commit():
+    """HEAD of this tree: SCM_GIT_COMMIT, `git rev-parse`, or build/git_commit (written by __graft_entry__.build();
+    the GPU box receives no .git)."""
+    c = os.environ.get("SCM_GIT_COMMIT")
+    if c:
+        return c
+    try:
+        c = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
+    except Exception:
+        c = ""
+    if c:
+        return c
+    try:
+        return open(os.path.join(ROOT, "build", "git_commit")).read().strip() or None
+    except OSError:
+        return None
+
+
 def _sha16(path):
     try:
         return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
@@ -241,7 +259,7 @@ def _sha16(path):
         return None
 
 
-def measured_pmc(kernel_substr, source_file):
+def measured_pmc(kernel_substr, source_file, need="hbm_traffic_bytes"):
     """Newest committed PMC record (profiles/round*_pmc*.json) of a kernel whose source file is unchanged."""
     import glob
     sha = _sha16(os.path.join(ROOT, "scm_gan_amd", "csrc", source_file))
@@ -253,7 +271,7 @@ def measured_pmc(kernel_substr, source_file):
         if pmc.get("kernel_source_sha16", {}).get(source_file) != sha:
             continue
         for k, v in pmc.get("kernels", {}).items():
-            if kernel_substr in k and "hbm_traffic_bytes" in v:
+            if kernel_substr in k and need in v:
                 return dict(v, _file=os.path.basename(f), _kernel=k, _commit=pmc.get("git_commit"))
     return None
 
@@ -280,8 +298,62 @@ def measured_traffic(kernel_name):
         for k, v in pmc.get("kernels", {}).items():
             if want in k and "hbm_traffic_bytes" in v:
                 return {"bytes": v["hbm_traffic_bytes"], "kernel": k, "file": os.path.basename(f),
-                        "kernel_source_sha16": sha, "measured_at_commit": pmc.get("git_commit")}
+                        "kernel_source_sha16": sha, "measured_at_commit": pmc.get("git_commit"),
+                        "mfma_busy": v.get("mfma_utilisation"), "duration_us_median": v.get("duration_us_median")}
     return None
+
+
+def encoder_leg(dev, batch):
+    """North star: "MFMA utilisation on the encoder convs".  The encoder's forward (its four launches: conv1 9 -> 128,
+    conv2 / conv3 128 -> 128, conv4 128 -> 16, zero padding) in isolation, every launch bracketed by HIP events on its
+    stream.  Per launch: microseconds, algorithmic TFLOP/s (2 x 9 MACs per output and input channel) and ISSUED
+    TFLOP/s on the f32 MFMA pipe (Winograd F(2x2,3x3) launches issue 4/9 of the products) as a fraction of the
+    pipe's peak; `mfma_busy_pmc` = SQ_VALU_MFMA_BUSY_CYCLES share of the same instantiations from the newest
+    rocprofv3 --pmc pass under profiles/ whose kernel sources are this tree's (null otherwise)."""
+    from scm_gan_amd import models, ops
+    torch.manual_seed(0)
+    enc = models.Encoder(L, C)
+    x = (torch.rand(batch, 3, C, H, W, device=dev) < 0.1).float()
+    reps = 10
+    with torch.no_grad():
+        for _ in range(3):
+            enc(x)
+        timer = ops.KernelTimer()
+        ops.kernel_timer = timer
+        try:
+            for _ in range(reps):
+                enc(x)
+        finally:
+            ops.kernel_timer = None
+    torch.cuda.synchronize()
+    per = len(timer.records) // reps
+    names = ["conv1", "conv2", "conv3", "conv4"] if per == 4 else ["launch%d" % i for i in range(per)]
+    peak = PEAK_F32_MFMA_TFLOPS if ops.compute_precision() == "fp32" else PEAK_F16_MFMA_TFLOPS
+    layers, tot_us, tot_issued, tot_alg = [], 0.0, 0.0, 0.0
+    pmc_names = {"conv1": ("conv3x3_wino_k16_kernel<1, 0, 0", "conv3x3_wino_k16.hip"),
+                 "conv2": ("conv3x3_wino_kernel<1, 0, 0, 128>", "conv3x3_wino.hip"),
+                 "conv3": ("conv3x3_wino_kernel<1, 0, 0, 128>", "conv3x3_wino.hip"),
+                 "conv4": ("conv3x3_wino16_kernel<2, 0", "conv3x3_wino16.hip")}
+    for i, nm in enumerate(names):
+        recs = timer.records[i::per]
+        us = sum(s.elapsed_time(e) for _, _, s, e in recs) * 1e3 / len(recs)
+        tag, flops = recs[0][0], recs[0][1]
+        issued = flops * (4.0 / 9.0 if "wino" in tag else 1.0)
+        e = {"layer": nm, "kernel": tag, "us": us, "algorithmic_tflops": flops / us / 1e6,
+             "issued_tflops": issued / us / 1e6, "issued_frac_of_peak": issued / us / 1e6 / peak, "mfma_busy_pmc": None}
+        if nm in pmc_names and "wino" in tag and (H, W, batch) == (64, 64, 64):
+            pmc = measured_pmc(*pmc_names[nm], need="mfma_utilisation")
+            if pmc is not None:
+                e["mfma_busy_pmc"] = pmc.get("mfma_utilisation")
+                e["mfma_busy_pmc_source"] = pmc["_file"]
+        layers.append(e)
+        tot_us += us
+        tot_issued += issued
+        tot_alg += flops
+    return {"launches": layers, "us_total": tot_us, "algorithmic_tflops": tot_alg / tot_us / 1e6,
+            "issued_tflops": tot_issued / tot_us / 1e6, "issued_frac_of_peak": tot_issued / tot_us / 1e6 / peak,
+            "peak_tflops": peak, "target": "north star: >= 0.50 MFMA utilisation on the encoder convs",
+            "note": "issued = FLOPs the MFMA pipe executes (4/9 of the algorithmic ones in the Winograd launches)"}
 
 
 def self_launch(gpus, argv):
@@ -380,17 +452,40 @@ def main():
     timer = ops.KernelTimer() if (not a.no_kernel_timer and rank == 0) else None
     barrier()
     t0 = time.perf_counter()
+    fired0 = trainer.sync.hook_fired
     for i in range(a.steps):
         ops.kernel_timer = timer if i % 10 == 0 else None
+        trainer.sync.timing = trainer.sync.enabled and i % 10 == 5       # collective brackets: every 10th step too
         trainer.step(*batches[i % 2], theta=0.5, train_iter=a.warmup + i + 1)
+    torch.cuda.synchronize()
+    dt_own = time.perf_counter() - t0          # this rank alone, before the closing barrier
     barrier()
     dt = time.perf_counter() - t0
     ops.kernel_timer = None
+    trainer.sync.timing = False
+    dist_info = None
     if world > 1 or under_launcher:
         import torch.distributed as dist
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # what the process group really looked like (for the day the 8-GPU run happens): every rank's device,
+        # its own step time, whether its hook issued the early buckets, and the collectives' cost
+        mine = torch.tensor([float(rank), float(torch.cuda.current_device()), dt_own / a.steps * 1e3,
+                             float(trainer.sync.hook_fired - fired0)], device=dev, dtype=torch.float64)
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        rows = [r.tolist() for r in allr]
+        dist_info = {"backend": dist.get_backend(), "ranks_seen": dist.get_world_size(),
+                     "devices_seen": sorted(int(r[1]) for r in rows),
+                     "rank_ms_per_step": {"min": min(r[2] for r in rows), "max": max(r[2] for r in rows),
+                                          "per_rank": [round(r[2], 3) for r in sorted(rows)]},
+                     "hook_fired": [int(r[3]) for r in sorted(rows)], "timed_steps": a.steps,
+                     "grad_sync_enabled": bool(trainer.sync.enabled),
+                     "allreduce_us": trainer.sync.timing_summary() if trainer.sync.enabled else None,
+                     "allreduce_buckets": {"early": [f.name for f in trainer.sync.early],
+                                           "late": [f.name for f in trainer.sync.late],
+                                           "bytes": {f.name: 4 * f.flat.numel() for f in trainer.flats}}}
 
     if rank == 0:
         frames = a.batch * world * (a.horizon - 2) * a.steps
@@ -404,7 +499,7 @@ def main():
                                 "f32 accumulate; error vs float64 = the native f32 kernel's); weight gradients and thin layers "
                                 "native f32",
                       "fp16": "f16 fwd / bf16 bwd MFMA operands, f32 accumulate + f32 tensors"}[a.precision],
-            "data": "synthetic",
+            "data": "synthetic", "git_commit": git_commit(),
             "config": {"workload": "%s: %dx%dx%d frames, per-GPU batch %d, horizon %d, A=%d, R=%d, "
                                    "training iteration fwd+bwd+clip+Adam, reference loss (BCE + reward MSE), %s"
                                    % ("configs[1] minipacman-shaped" if headline else
@@ -430,6 +525,8 @@ def main():
             "executed_frac_of_f32_mfma_peak": (value / world * executed_gflop_per_frame(a.horizon) / 1e3 / PEAK_F32_MFMA_TFLOPS
                                                if a.precision == "fp32" else None),
         }
+        if dist_info is not None:
+            out["distributed"] = dist_info
         if timer is not None:
             summ = timer.summary()
             dom = max(summ.items(), key=lambda kv: kv[1]["ms"])
@@ -442,20 +539,28 @@ def main():
             peak = PEAK_F16_MFMA_TFLOPS if "h16" in name else (PEAK_F16_MFMA_TFLOPS / 6.0 if "x3_kernel" in name
                                                              else PEAK_F32_MFMA_TFLOPS)
             wino = "wino" in name
-            out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": peak,
-                               "unit": "TFLOP/s", "frac": achieved / peak,
+            # `achieved` = FLOPs the MFMA pipe EXECUTES per second in the dominant kernel, so `frac` is a fraction of the
+            # pipe (<= 1).  For the direct kernels that is the algorithmic count (2 x 9 MACs per output and input
+            # channel); Winograd F(2x2,3x3) issues 16 products per 2x2 output patch and channel pair instead of 36,
+            # i.e. 4/9 of it -- the algorithmic (direct-convolution-equivalent) rate is reported beside it.
+            issued = achieved * (4.0 / 9.0 if wino else 1.0)
+            launch_b, launch_hw = a.batch, H * W
+            out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": issued, "peak": peak,
+                               "unit": "TFLOP/s", "frac": issued / peak,
+                               "algorithmic_tflops": achieved, "algorithmic_over_issued": achieved / issued,
                                "traffic": tr_info["bytes"] if tr_info else None, "traffic_source": tr_info,
                                "launches": s["launches"], "avg_launch_us": s["ms"] * 1e3 / s["launches"],
                                # brackets are recorded on every 10th timed step: scale to the whole timed region
                                "share_of_step": s["ms"] / (dt * 1e3) * a.steps / len(range(0, a.steps, 10))}
+            if tr_info and (H, W, a.batch) == (64, 64, 64):
+                # the PMC case is the 128 -> 128 launch at B = 64, 64x64: read x + write y, 4 bytes each
+                alg_bytes = 2.0 * launch_b * 128 * launch_hw * 4
+                out["roofline"]["traffic_algorithmic_bytes"] = alg_bytes
+                out["roofline"]["traffic_ratio"] = tr_info["bytes"] / alg_bytes
+                out["roofline"]["mfma_busy_pmc"] = tr_info.get("mfma_busy")
             if wino:
-                # `achieved` counts the ALGORITHMIC FLOPs of the convolution (2 * 9 MACs per output and input channel);
-                # Winograd F(2x2,3x3) issues 4/9 of them on the f32 MFMA pipe, so `frac` can exceed 1 -- the share of
-                # the pipe's peak the kernel really keeps busy is mfma_executed_frac
                 out["roofline"]["algorithm"] = ("Winograd F(2x2,3x3), fp32 operands / fp32 accumulate: 16 MFMA products per "
                                                 "2x2 output patch and channel pair instead of 36")
-                out["roofline"]["mfma_executed_tflops"] = achieved * 4.0 / 9.0
-                out["roofline"]["mfma_executed_frac"] = achieved * 4.0 / 9.0 / peak
             out["kernels"] = {k: {"launches": v["launches"], "ms_total": round(v["ms"], 3),
                                   "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12} for k, v in summ.items()}
         if world == 1 and not a.profile_mode and a.precision == "fp32" and a.size <= 64:
@@ -472,6 +577,7 @@ def main():
                 os.environ.pop("SCM_X3_ANY_BATCH", None)
         if world == 1 and not a.profile_mode:
             out["decoder"] = decoder_leg(dev, a.batch)
+            out["encoder"] = encoder_leg(dev, a.batch)
         if world == 1 and headline and not a.profile_mode:
             l1, flips = rollout_l1(dev)
             out["rollout_l1_vs_ref"] = l1

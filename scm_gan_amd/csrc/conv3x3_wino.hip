@@ -798,7 +798,8 @@ extern "C" int scm_conv3x3_wino(const scm_conv3x3_desc* d, void* stream) {
     k.mask_in = d->gate_mask_in;
     k.acc_y1 = d->accumulate_y1;
     k.ymask1 = d->gate_mask_y1; k.ymask2 = d->gate_mask_y2;
-    SCM_REQUIRE((!d->gate_mask_y1 || (d->co1 & 31) == 0 || d->co1 == d->cout) && ((reinterpret_cast<size_t>(d->gate_mask_y1) | reinterpret_cast<size_t>(d->gate_mask_y2)) & 7) == 0,
+    // (either mask: the epilogue indexes gate_mask_y2 by (co - co1) >> 5 with the bit = the row inside the wave's 32 channels)
+    SCM_REQUIRE(((!d->gate_mask_y1 && !d->gate_mask_y2) || (d->co1 & 31) == 0 || d->co1 == d->cout) && ((reinterpret_cast<size_t>(d->gate_mask_y1) | reinterpret_cast<size_t>(d->gate_mask_y2)) & 7) == 0,
                 "scm_conv3x3_wino: output gates need co1 %% 32 == 0 and 8-byte aligned masks");
     k.mask_out = (d->act == SCM_ACT_LRELU && d->cout > 32) ? d->gate_mask_out : nullptr;
     SCM_REQUIRE(!d->gate_mask_out || k.mask_out, "scm_conv3x3_wino: gate_mask_out needs act == LRELU and cout > 32");
@@ -819,7 +820,9 @@ extern "C" int scm_conv3x3_wino(const scm_conv3x3_desc* d, void* stream) {
     // 128-channel groups, one output tensor per group and the patch rows tile 32 patches
     static const int no128 = getenv("SCM_WINO_NO128") ? atoi(getenv("SCM_WINO_NO128")) : 0;
     const int tcw = d->W / 2;
-    const bool cw128 = !no128 && (d->cout & 127) == 0 && (d->co1 & 31) == 0 && tcw <= 32 && 32 % tcw == 0 && ntiles % 32 == 0;
+    // (one raw pixel pair per thread: the halo rows of 32 patches must fit 512 floats per channel -- W = 2 with H > 62 does not)
+    const bool cw128 = !no128 && (d->cout & 127) == 0 && (d->co1 & 31) == 0 && tcw <= 32 && 32 % tcw == 0 && ntiles % 32 == 0 &&
+                       wino_plane(d->H, d->W, 32) <= 512;
     const int tw = cw128 ? 32 : WINO_TILES;
     k.tiles_per_img = (ntiles + tw - 1) / tw;
     k.plane = wino_plane(d->H, d->W, tw);

@@ -126,6 +126,10 @@ class GradSync(object):
         self._main = None
         self._comm = torch.cuda.Stream() if enabled else None
         self.hook_fired = 0          # diagnostics / tests: how many iterations issued early
+        # diagnostics (bench.py `allreduce_us`): with `timing` on, every issue is bracketed by HIP events on the
+        # communication stream, which then itself waits for the collectives (RCCL runs them on its own stream)
+        self.timing = False
+        self.timings = []            # (tag, start event, end event)
 
     def arm(self, z):
         self._works, self._early_issued = [], False
@@ -134,17 +138,34 @@ class GradSync(object):
         self._main = torch.cuda.current_stream()
         z.register_hook(self._on_first_latent_grad)
 
-    def _issue(self, buckets):
+    def _issue(self, buckets, tag):
         self._comm.wait_stream(self._main)          # everything enqueued so far on the training stream
         with torch.cuda.stream(self._comm):
-            for b in buckets:
-                self._works.append(b.all_reduce(async_op=True))
+            if self.timing:
+                start = torch.cuda.Event(enable_timing=True)
+                start.record()
+            works = [b.all_reduce(async_op=True) for b in buckets]
+            if self.timing:
+                for w in works:
+                    w.wait()                        # stream-side: the communication stream waits for RCCL's
+                end = torch.cuda.Event(enable_timing=True)
+                end.record()
+                self.timings.append((tag, start, end))
+            self._works += works
+
+    def timing_summary(self):
+        """{'early' / 'late' / 'all': mean microseconds between issue and completion on the communication stream}."""
+        torch.cuda.synchronize()
+        acc = {}
+        for tag, s, e in self.timings:
+            acc.setdefault(tag, []).append(s.elapsed_time(e) * 1e3)
+        return {k: sum(v) / len(v) for k, v in acc.items()}
 
     def _on_first_latent_grad(self, grad):
         if not self._early_issued:
             self._early_issued = True
             self.hook_fired += 1
-            self._issue(self.early)
+            self._issue(self.early, "early")
         return None
 
     def finish(self):
@@ -153,7 +174,10 @@ class GradSync(object):
             return
         if self._main is None:
             self._main = torch.cuda.current_stream()
-        self._issue(self.late if self._early_issued else self.early + self.late)
+        if self._early_issued:
+            self._issue(self.late, "late")
+        else:
+            self._issue(self.early + self.late, "all")
         for w in self._works:
             w.wait()
         self._works = []

@@ -393,6 +393,16 @@ def pregate_ok(H, W):
             and WINO_MIN_CIN <= 16 and WINO_MIN_COUT <= 64 and wino_serves(H, W))
 
 
+def _gate_by_mask(dx, mask):
+    """dx * leaky-relu slope of the activation whose 1-bit gate mask (B, ceil(C/32), H, W) this is."""
+    if dx is None or mask is None:
+        return dx
+    C = dx.shape[1]
+    ch = torch.arange(C, device=dx.device)
+    bits = (mask[:, ch // 32] >> (ch % 32).to(torch.int32).view(1, C, 1, 1)) & 1
+    return dx * torch.where(bits.bool(), 1.0, 0.01).to(dx.dtype)      # models.py: leaky_relu default slope
+
+
 # -------------------------------------------------------------- conv 3x3
 class Conv3x3Fn(Function):
     """y = act(conv3x3(cat(x1, x2), W_eff) + bias [+ action-plane bias]),
@@ -478,11 +488,19 @@ class Conv3x3Fn(Function):
             if dprec == ALGO_WINO and c1 + c2 <= 16 and (act or acc1 is not None or c2):
                 dpack, dprec = cfg["packs"][5], PREC_F32          # (the 16-row form takes ungated, plain-store launches)
             if (in_masks[0] is not None or in_masks[1] is not None) and dprec != ALGO_WINO:
-                raise RuntimeError("scm_gan_amd.conv3x3.backward: producer-side gating needs the Winograd input-gradient "
-                                   "kernel (ops.pregate_ok)")
-            dx1, dx2 = _conv3x3_raw(gy, None, y if act else None, None, act, dpack, c1 + c2, inv_sigma, None, None, c1,
-                                    cfg["pad"], ACT_NONE, dprec, mask_in=gmask, y1_acc=acc1, ymask1=in_masks[0],
-                                    ymask2=in_masks[1])
+                # The chain was forwarded with producer-side gating (ops.pregate_ok looks at the frame), but THIS layer's
+                # input gradient left the Winograd kernel (a latent_size below its channel minimum, an oddly offset
+                # gradient view): the direct kernel writes the ungated gradient and the destination's slopes are applied
+                # from its 1-bit mask here, before anything is added to a shared buffer -- rare, correct, not fast.
+                dx1, dx2 = _conv3x3_raw(gy, None, y if act else None, None, act, dpack, c1 + c2, inv_sigma, None, None,
+                                        c1, cfg["pad"], ACT_NONE, dprec, mask_in=gmask)
+                dx1, dx2 = _gate_by_mask(dx1, in_masks[0]), _gate_by_mask(dx2, in_masks[1])
+                if acc1 is not None:
+                    dx1 = acc1.add_(dx1)
+            else:
+                dx1, dx2 = _conv3x3_raw(gy, None, y if act else None, None, act, dpack, c1 + c2, inv_sigma, None, None, c1,
+                                        cfg["pad"], ACT_NONE, dprec, mask_in=gmask, y1_acc=acc1, ymask1=in_masks[0],
+                                        ymask2=in_masks[1])
             if cell1 is not None:
                 cell1["buf"] = dx1
             if cell2 is not None and dx2 is not None:

@@ -1,5 +1,6 @@
 """smoke(): one small encoder -> fused decoder + loss -> transition step with backward
-on cuda:0 through the C ABI, checked against the CPU oracle."""
+on cuda:0 through the C ABI, checked against the CPU oracle.  Lives next to __graft_entry__.py, outside
+the product package: nothing under scm_gan_amd/ imports the oracle."""
 import os
 import sys
 
@@ -8,7 +9,7 @@ import torch
 
 
 def smoke():
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    root = os.path.dirname(os.path.abspath(__file__))
     for p in (root, os.path.join(root, "tests", "golden")):
         if p not in sys.path:
             sys.path.insert(0, p)

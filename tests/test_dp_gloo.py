@@ -110,7 +110,9 @@ def _batch(gan):
 
 
 def _flags(case):
-    return {"default": [], "lo": ["--latent-overshooting"], "gan": ["--gan"], "no_overlap": ["--no-overlap"]}[case]
+    cf = ["--enable-disentanglement-loss", "--enable-action-control-loss"]
+    return {"default": [], "lo": ["--latent-overshooting"], "gan": ["--gan"], "no_overlap": ["--no-overlap"],
+            "cf": cf, "cf_no_overlap": cf + ["--no-overlap"]}[case]
 
 
 def _run_step(case, shard, steps=2):
@@ -124,6 +126,7 @@ def _run_step(case, shard, steps=2):
     opts = M.parser.parse_args(["--train-iters", "10", "--horizon-min", str(HORIZON), "--horizon-max", str(HORIZON)]
                                + _flags(case))
     trainer = M.Trainer(L, A, R, enc, dec, rp, disc, tr, opts)
+    np.random.seed(1234)            # (the counterfactual regularisers draw factor pairs / action shuffles from numpy's global stream)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a[shard]))
     oh = torch.eye(A)[torch.from_numpy(actions[shard])]
     for it in range(steps):
@@ -162,6 +165,41 @@ def test_trainer_step_two_ranks_equal_full_batch(case):
         err = (w - ref_w).abs()
         assert float(err.max()) <= 4.1e-4 and float((err < 2e-6).float().mean()) > 0.995, (case, float(err.max()))
     assert torch.equal(out[0][1], out[1][1])                           # replicas stay bit-identical
+
+
+def _cf_worker(rank, world, port, out):
+    _init(rank, world, port)
+    half = B // world
+    shard = slice(rank * half, (rank + 1) * half)
+    res = {}
+    for case in ("cf", "cf_no_overlap"):
+        # five iterations: the counterfactual terms enter on train_iter % CF_REGULARIZATION_RATE == 0 (main.py:242,268)
+        grads, weights, fired, trainer = _run_step(case, shard, steps=5)
+        assert trainer.a.enable_disentanglement_loss and trainer.a.enable_action_control_loss
+        res[case] = (grads, weights, fired)
+    out[rank] = res
+    dist.destroy_process_group()
+
+
+def test_counterfactual_losses_overlapped_buckets_equal_no_overlap():
+    """GradSync's hook relies on the autograd engine finishing every node created after the first
+    encoder call before the first latent's gradient arrives.  The counterfactual regularisers (main.py:242-283) add
+    consumers of that latent -- z_orig = z.clone(), mutated in place, rolled forward twice more through the
+    transition -- AFTER the unrolled loop: with them on, the buckets reduced early from the hook must equal the
+    buckets reduced after backward() (--no-overlap), on both ranks, in the iteration where the terms are active."""
+    _paths()
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_cf_worker, args=(world, _port(), out), nprocs=world, join=True)
+    for r in range(world):
+        g_o, w_o, fired_o = out[r]["cf"]
+        g_n, w_n, fired_n = out[r]["cf_no_overlap"]
+        assert fired_o == 5 and fired_n == 0
+        assert float(g_o.abs().max()) > 0
+        assert torch.equal(g_o, g_n), float((g_o - g_n).abs().max())
+        assert torch.equal(w_o, w_n)
+    assert torch.equal(out[0]["cf"][1], out[1]["cf"][1])               # replicas stay bit-identical
 
 
 # ----------------------------------------------------- u / v across an evaluation boundary

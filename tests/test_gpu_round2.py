@@ -256,3 +256,36 @@ def test_rccl_one_rank_overlapped_allreduce(monkeypatch):
     finally:
         dp.shutdown()
     assert torch.equal(w_plain, w_sync)
+
+
+def test_bench_line_under_the_launcher_is_self_diagnosing():
+    """bench.py as the driver starts it for N > 1 (`python -m torch.distributed.run ... bench.py --gpus N`), here with
+    one rank and SCM_FORCE_ALLREDUCE=1 so the RCCL collectives run: the JSON line must say what the process group
+    looked like -- backend, ranks and devices seen, every rank's own step time, whether the hook issued the early
+    buckets in every timed step, and the collectives' cost from HIP events on the communication stream."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(SCM_FORCE_ALLREDUCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "12", "--warmup", "2",
+           "--batch", "8", "--horizon", "5", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    d = out["distributed"]
+    assert d["backend"] == "nccl" and d["ranks_seen"] == 1 and d["devices_seen"] == [0]
+    assert d["grad_sync_enabled"] and d["hook_fired"] == [12] and d["timed_steps"] == 12
+    assert set(d["allreduce_us"]) == {"early", "late"} and all(v > 0 for v in d["allreduce_us"].values())
+    assert d["allreduce_buckets"]["early"] == ["decoder", "transition", "reward_predictor"]
+    assert d["allreduce_buckets"]["late"] == ["encoder"]
+    assert d["rank_ms_per_step"]["min"] <= d["rank_ms_per_step"]["max"] <= out["ms_per_step"] * 1.05
+    assert len(d["rank_ms_per_step"]["per_rank"]) == 1
+    assert out["n_gpus"] == 1 and out["roofline"]["frac"] <= 1.0

@@ -16,7 +16,7 @@ for f in glob.glob(os.path.join(root, '**', '*kernel_trace.csv'), recursive=True
         dur.setdefault(r['Kernel_Name'], []).append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
 out = {}
 for k, c in vals.items():
-    if 'pack_' in k or not any(t in k for t in ('conv3x3_mfma', 'conv3x3_h16', 'conv3x3_x3', 'conv3x3_wgrad', 'conv3x3_wino', 'decoder_fused_fwd', 'decoder_fused_bwd')):
+    if 'pack_' in k or not any(t in k for t in ('conv3x3_mfma', 'conv3x3_h16', 'conv3x3_x3', 'conv3x3_wgrad', 'conv3x3_wino', 'decoder_fused_fwd', 'decoder_fused_bwd', 'reward_fused', 'sn_power_iter')):
         continue
     e = {}
     if k in dur:
@@ -35,7 +35,7 @@ for k, c in vals.items():
 here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sha = {}
 for f in ('conv3x3_wino.hip', 'conv3x3_wgrad_wino.hip', 'conv3x3_wino16.hip', 'conv3x3_wgrad_wino16.hip', 'conv3x3_wino_k16.hip', 'conv3x3_mfma.hip', 'conv3x3_h16.hip', 'conv3x3_x3.hip', 'conv3x3_wgrad.hip', 'conv3x3_wgrad_h16.hip', 'conv3x3_wgrad_x3.hip',
-          'decoder_fused.hip'):
+          'decoder_fused.hip', 'reward_fused.hip', 'sn.hip'):
     try:
         sha[f] = hashlib.sha256(open(os.path.join(here, 'scm_gan_amd', 'csrc', f), 'rb').read()).hexdigest()[:16]
     except OSError:
@@ -44,6 +44,11 @@ try:
     commit = subprocess.run(['git', 'rev-parse', '--short', 'HEAD'], cwd=here, capture_output=True, text=True).stdout.strip() or None
 except Exception:
     commit = None
-json.dump({'kernel_source_sha16': sha, 'git_commit': commit or os.environ.get('SCM_GIT_COMMIT'), 'source': 'rocprofv3 --kernel-trace --pmc <FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE> -- python3 tools/prof_hot2.py (separate passes)',
+if not commit:
+    try:
+        commit = open(os.path.join(here, 'build', 'git_commit')).read().strip() or None     # written by __graft_entry__.build()
+    except OSError:
+        commit = None
+json.dump({'kernel_source_sha16': sha, 'git_commit': os.environ.get('SCM_GIT_COMMIT') or commit, 'source': 'rocprofv3 --kernel-trace --pmc <FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE> -- python3 tools/prof_hot2.py (separate passes)',
            'case': '128->128 channels, B=64, 64x64, circular padding, leaky-relu, 1-bit gate mask: forward, gated dgrad, wgrad; fp32 Winograd F(2x2,3x3) (the default), fp32 direct, fp32-on-the-bf16-pipe (x3) and 16-bit-operand kernels; fused decoder + BCE forward / backward at B=64, 64x64x3; since round 3 also the producer-gated Winograd forms (ungated weight gradient <0,1,0>) and the 16-channel-side layers of the transition (conv6 forward 256->16, its weight gradient and its input gradient 16->256, conv1 forward and weight gradient 16<->128); last dispatch of each kernel',
            'kernels': out}, sys.stdout, indent=1)

@@ -79,3 +79,17 @@ tgt = (torch.rand(B, 3, H, W, device='cuda') < 0.1).float()
 for _ in range(3):
     dec.forward_loss(z, tgt).mean().backward()
 torch.cuda.synchronize()
+# the encoder's forward as the training step launches it (zero padding: conv1 9 -> 128 on the 16-input-channel kernel,
+# conv2 / conv3 on the wide kernel's zero-padded instantiation, conv4 128 -> 16 on the 16-row kernel) -- the north star's
+# "MFMA utilisation on the encoder convs" -- and its backward
+enc = M.Encoder(16, 3)
+xe = (torch.rand(B, 3, 3, H, W, device='cuda') < 0.1).float()
+for _ in range(3):
+    enc(xe).sum().backward()
+torch.cuda.synchronize()
+# the fused reward head, forward + backward
+rp = M.RewardPredictor(16, 2)
+zr = (torch.rand(B, 16, H, W, device='cuda') < 0.5).float().requires_grad_(True)
+for _ in range(3):
+    rp(zr).sum().backward()
+torch.cuda.synchronize()
