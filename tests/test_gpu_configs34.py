@@ -106,7 +106,10 @@ def test_cfg5_fp16_mode_vs_oracle_teacher_forced(capsys):
     ops.set_compute_precision("fp16")
     try:
         enc, tr, dec, rp = hip_nets(states, C, A, R)
-        for m in (enc, tr, dec, rp):
+        # (SpectralNorm advances u / v on every forward: the free-running rollout gets its own transition replica, so
+        # that each replica makes exactly the calls the oracle's makes)
+        tr_free = hip_nets(states, C, A, R)[1]
+        for m in (enc, tr, tr_free, dec, rp):
             m.train()
         seen = {}
         tr.conv6.register_forward_hook(lambda m, i, o: seen.__setitem__("p", o.detach()))
@@ -141,8 +144,8 @@ def test_cfg5_fp16_mode_vs_oracle_teacher_forced(capsys):
                 assert fr < 1e-3, (t, "latent flip-rate", fr)
                 # free-running 16-bit rollout next to it (reported only)
                 free_l1.append(float((torch.sigmoid(dec(z_free)).cpu() - torch.sigmoid(oy)).abs().mean()))
-                tr.set_noise([up(noise[i])])
-                z_free = tr(z_free, up(onehot.numpy()))
+                tr_free.set_noise([up(noise[i])])
+                z_free = tr_free(z_free, up(onehot.numpy()))
                 oz = ozn
         with capsys.disabled():
             print("\n[cfg5 fp16 vs oracle, 128x128x4, h=20, teacher-forced] max |dlogit| %.2e, max flip-rate/step %.2e, "
