@@ -52,3 +52,8 @@ int scm_launch_wgrad_wino(const WgradKArgs& a, int max_splits, int* nsplit_out, 
 // v_mfma_f32_16x16x4_f32 with operands transformed in the lanes that feed them (conv3x3_wgrad_wino16.hip).
 bool scm_wgrad_wino16_serves(const WgradKArgs& a, int max_splits);
 int scm_launch_wgrad_wino16(const WgradKArgs& a, int max_splits, int* nsplit_out, int* spi_out, hipStream_t s);
+
+// The same tiles with the transforms written around the register pairs the loads deliver and a chunk walk that visits
+// both 64-byte halves of a line back to back (conv3x3_wgrad_winoz.hip); takes the first form's split as it is.
+bool scm_wgrad_winoz_serves(const WgradKArgs& a);
+int scm_launch_wgrad_winoz(const WgradKArgs& a, dim3 grid, hipStream_t s);

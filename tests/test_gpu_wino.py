@@ -27,7 +27,11 @@ WSHAPES = [
     (1, 64, 0, 64, 20, 12, 0, 1), (3, 64, 0, 48, 20, 12, 0, 0), (1, 128, 0, 128, 64, 64, 1, 1),
     (1, 100, 0, 128, 84, 84, 1, 1), (1, 128, 0, 128, 128, 128, 0, 1), (2, 70, 0, 70, 9, 8, 1, 1),
     (2, 70, 0, 70, 9, 8, 0, 2), (1, 64, 0, 64, 33, 24, 1, 0), (2, 64, 64, 100, 6, 8, 0, 1),
-    (1, 64, 0, 64, 2, 4, 1, 0), (4, 128, 0, 128, 32, 32, 1, 1), (1, 64, 0, 64, 10, 100, 0, 1)]
+    (1, 64, 0, 64, 2, 4, 1, 0), (4, 128, 0, 128, 32, 32, 1, 1), (1, 64, 0, 64, 10, 100, 0, 1),
+    # bands of several patch rows on frames with W % 32 == 0: the zigzag form (conv3x3_wgrad_winoz.hip) -- carried rows,
+    # role swaps, strip pairs, zero padding at the top / bottom band, two input tensors, ungated / float / 1-bit gates
+    (8, 128, 0, 128, 64, 64, 1, 1), (8, 64, 64, 128, 64, 64, 0, 1), (64, 64, 0, 64, 32, 32, 1, 0),
+    (3, 128, 0, 128, 128, 128, 0, 1), (2, 64, 0, 64, 64, 32, 0, 0)]
 
 
 @pytest.fixture(scope="module")
