@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wgrad_wino16_kernel(const Wgra
     const int c = lane & 15, p = lane >> 4;
     const int W = a.W, H = a.H, HW = H * W;
     const int TRH = H >> 1, TCW = W >> 1;
-    const int xparts = W >> 5;
+    const int xparts = (W + 31) >> 5;                // (the last 32-column part of a row may be ragged: W % 4 == 0)
 
     int split, wg;                                   // wg: 32-channel group of the wide side
     scm_xcd_split_group(a.spi, split, wg);
@@ -109,8 +109,15 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wgrad_wino16_kernel(const Wgra
     const int sdc = DT == 2 ? tid >> 3 : (tid >> 3) & 15, sdr = DT == 2 ? 0 : wave >> 1;
     int cxi = g0x + sxc; if (cxi > cin - 1) cxi = cin - 1;      // (a channel past the end: computed, never stored)
     int cdi = g0d + sdc; if (cdi > a.cout - 1) cdi = a.cout - 1;
-    unsigned sxoff = (unsigned)(cxi - g0x) * (unsigned)plane_b + (unsigned)(x0 + 4 * sk) * 4u;
-    unsigned sdoff = (unsigned)(cdi - g0d) * (unsigned)plane_b + (unsigned)(x0 + 4 * sk) * 4u;
+    // A 4-column chunk past the end of a ragged last part: its output gradient is staged as zeros (the patches do not
+    // exist), its input columns are read from columns 0 .. 3 of the row -- the chunk that starts AT column W thereby
+    // delivers the wrapped border column (index W - x0 + 1 of the staged row) of the last real patch; with zero padding
+    // it is staged as zeros.
+    const bool svalid = x0 + 4 * sk < W;
+    const int scol = svalid ? x0 + 4 * sk : 0;
+    const float sxz = (svalid || PADC) ? 1.f : 0.f, sdz = svalid ? 1.f : 0.f;
+    unsigned sxoff = (unsigned)(cxi - g0x) * (unsigned)plane_b + (unsigned)scol * 4u;
+    unsigned sdoff = (unsigned)(cdi - g0d) * (unsigned)plane_b + (unsigned)scol * 4u;
     float* const sxl = XL + (sxr * XC + sxc) * XP + 1 + 4 * sk;     // (+ XC * XP for the second row when XT == 2)
     float* const sdl = DL + (sdr * DC + sdc) * 32 + 4 * sk;
     const bool hrole = tid < 2 * XC;
@@ -186,7 +193,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wgrad_wino16_kernel(const Wgra
 #pragma unroll
         for (int i = 0; i < (XT == 2 ? 2 : 1); ++i) {
             f32x4 v = gx[Q][i];
-            if constexpr (PADC == 0) v *= (XT == 2 ? (i ? zb : za) : (sxr ? zb : za));
+            if constexpr (PADC == 0) v *= (XT == 2 ? (i ? zb : za) : (sxr ? zb : za)) * sxz;
             float* d = xs + i * XC * XP;             // (index 1 + 4k is odd: two ds_write2_b32)
             d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
         }
@@ -197,7 +204,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wgrad_wino16_kernel(const Wgra
             hl[Q * XSL + XC * XP] = vb;
         }
         // the output gradient of patch row j - 1 (step s - 1), gated, zero past the end of the band
-        const float lv = (s >= 1 && s - 1 < nst) ? 1.f : 0.f;
+        const float lv = (s >= 1 && s - 1 < nst) ? sdz : 0.f;
 #pragma unroll
         for (int i = 0; i < (DT == 2 ? 2 : 1); ++i) {
             f32x4 v = gd[Q][i] * lv;
@@ -374,28 +381,29 @@ static int launch_w16(const WgradKArgs& a, dim3 grid, hipStream_t s) {
     return SCM_OK;
 }
 
-// Shapes the kernel takes: at most 16 channels on one side, rows of whole 32-pixel groups, even height, ungated or
+// Shapes the kernel takes: at most 16 channels on one side, rows of whole 4-pixel groups (at least 32 pixels: the last
+// 32-column part may be ragged -- 84 x 84, BASELINE configs[3]), even height, ungated or
 // float-gated output gradient (a 1-bit gate goes to the direct kernel), 8-byte aligned output gradient; a wide input
 // side split over two tensors in whole 32-channel groups; one split per (image, 32-column part) at least.
 bool scm_wgrad_wino16_serves(const WgradKArgs& a, int max_splits) {
     const int cin = a.c1 + a.c2;
     const bool thin_co = a.cout <= 16, thin_ci = cin <= 16;
     if (!thin_co && !thin_ci) return false;
-    if (a.W < 32 || (a.W & 31) || a.H < 2 || (a.H & 1)) return false;
+    if (a.W < 32 || (a.W & 3) || a.H < 2 || (a.H & 1)) return false;
     if (a.gate_act != 0 && (a.gate_mask != nullptr || a.gate == nullptr)) return false;
     if ((reinterpret_cast<size_t>(a.dy) | reinterpret_cast<size_t>(a.gate)) & 7) return false;
     if ((reinterpret_cast<size_t>(a.x1) | reinterpret_cast<size_t>(a.x2)) & 3) return false;
     if (thin_co ? (a.c2 != 0 && (a.c1 & 31) != 0) : a.c2 != 0) return false;
     // 32-bit lane offsets: 32 channel planes
     if ((size_t)a.H * a.W * 4 * 32 >= (1ull << 31)) return false;
-    return a.B * (a.W >> 5) <= max_splits;
+    return a.B * ((a.W + 31) >> 5) <= max_splits;
 }
 
 // One workgroup per (split = image x band of patch rows x 32-column part, 32-channel group of the wide side);
 // `max_splits`: what the caller's workspaces were sized for.
 int scm_launch_wgrad_wino16(const WgradKArgs& k, int max_splits, int* nsplit_out, int* spi_out, hipStream_t s) {
     WgradKArgs a = k;
-    const int cin = a.c1 + a.c2, trh = a.H / 2, xparts = a.W / 32;
+    const int cin = a.c1 + a.c2, trh = a.H / 2, xparts = (a.W + 31) / 32;
     const bool thin_co = a.cout <= 16;
     const int groups = thin_co ? (cin + 31) / 32 : (a.cout + 31) / 32;
     const int per_band = a.B * xparts * groups;

@@ -376,7 +376,8 @@ static inline int w16_plane(int H, int W) {
     return (2 * trows + 2) * (W + 6);
 }
 
-bool scm_wino16_serves(int H, int W) { return H >= 2 && W >= 2 && (W & 1) == 0 && w16_plane(H, W) <= 2 * 512; }
+// (three pixel pairs per thread and channel at most: 84 x 84 frames -- BASELINE configs[3] -- need 1 080 floats per channel)
+bool scm_wino16_serves(int H, int W) { return H >= 2 && W >= 2 && (W & 1) == 0 && w16_plane(H, W) <= 3 * 512; }
 
 template <int NJ, int PADC>
 static int launch_w16(const ConvKArgs& a, hipStream_t s) {
@@ -397,5 +398,6 @@ int scm_launch_wino16(const ConvKArgs& k, hipStream_t s) {
     a.plane = w16_plane(a.H, a.W);
     const bool circ = a.pad_mode == SCM_PAD_CIRCULAR;
     if (a.plane <= 512) return circ ? launch_w16<1, 1>(a, s) : launch_w16<1, 0>(a, s);
-    return circ ? launch_w16<2, 1>(a, s) : launch_w16<2, 0>(a, s);
+    if (a.plane <= 1024) return circ ? launch_w16<2, 1>(a, s) : launch_w16<2, 0>(a, s);
+    return circ ? launch_w16<3, 1>(a, s) : launch_w16<3, 0>(a, s);
 }

@@ -154,7 +154,8 @@ def test_forward_and_input_gradient_vs_float64(K, B, c1, c2, cout, H, W, pad, ac
 
 THIN = [  # B, c1, c2, cout <= 16, H, W, circular, act: the 16-row form's forward
     (2, 128, 128, 16, 16, 16, 1, 2), (2, 128, 0, 16, 16, 16, 0, 2), (1, 40, 0, 16, 20, 12, 1, 0), (2, 64, 0, 3, 9, 8, 0, 1),
-    (1, 128, 128, 16, 64, 64, 1, 2), (1, 32, 0, 16, 128, 128, 0, 0), (1, 32, 8, 12, 33, 22, 1, 2), (3, 128, 0, 16, 32, 32, 1, 0)]
+    (1, 128, 128, 16, 64, 64, 1, 2), (1, 32, 0, 16, 128, 128, 0, 0), (1, 32, 8, 12, 33, 22, 1, 2), (3, 128, 0, 16, 32, 32, 1, 0),
+    (2, 128, 128, 16, 84, 84, 1, 2), (2, 128, 0, 16, 84, 84, 0, 2), (1, 40, 0, 5, 84, 84, 1, 1)]
 
 
 @pytest.mark.parametrize("B,c1,c2,cout,H,W,pad,act", THIN)
@@ -174,7 +175,7 @@ def test_sixteen_channel_form_vs_float64(K, B, c1, c2, cout, H, W, pad, act):
         y, _ = K.conv(wino, x1.cuda(), None if x2 is None else x2.cuda(), fp, cout, pad, act, bias=b.cuda(), scale=sc.cuda())
         err[wino] = float((y.cpu().double() - yr).abs().max())
     assert err[1] < 1e-5 and err[1] <= 2.0 * err[0] + 1e-7, err
-    assert K.lib.scm_conv3x3_wino16_serves(84, 84) == 0          # (its 128-patch rows do not fit: the direct kernel runs)
+    assert K.lib.scm_conv3x3_wino16_serves(84, 84) == 1          # (three pixel pairs per thread: BASELINE configs[3] frames)
 
 
 @pytest.mark.parametrize("B,c1,c2,cout,H,W,pad,act", WSHAPES)
@@ -245,7 +246,10 @@ WTHIN = [  # B, c1, c2, cout, H, W, circular, act: at most 16 channels on one si
     # it hands to the direct kernel (W % 32 != 0)
     (2, 128, 128, 16, 64, 64, 1, 2), (2, 16, 0, 128, 64, 64, 1, 0), (2, 128, 0, 16, 32, 32, 0, 2), (1, 16, 0, 128, 32, 64, 0, 1),
     (3, 40, 0, 9, 8, 32, 1, 0), (2, 9, 0, 70, 6, 32, 1, 1), (1, 64, 32, 12, 16, 128, 1, 1), (2, 16, 0, 16, 34, 32, 0, 0),
-    (1, 128, 0, 16, 128, 128, 1, 2), (5, 16, 0, 128, 64, 64, 1, 0), (2, 128, 0, 16, 20, 12, 1, 0), (1, 16, 0, 64, 84, 84, 1, 1)]
+    (1, 128, 0, 16, 128, 128, 1, 2), (5, 16, 0, 128, 64, 64, 1, 0), (2, 128, 0, 16, 20, 12, 1, 0), (1, 16, 0, 64, 84, 84, 1, 1),
+    # ragged last 32-column part (W % 4 == 0, W > 32): 84 x 84 (BASELINE configs[3]) in both directions, both paddings, gates
+    (2, 128, 128, 16, 84, 84, 1, 2), (2, 16, 0, 128, 84, 84, 1, 0), (2, 128, 0, 16, 84, 84, 0, 2), (1, 9, 0, 128, 84, 84, 0, 1),
+    (2, 64, 0, 16, 10, 36, 1, 1), (1, 16, 0, 96, 12, 60, 0, 0)]
 
 
 @pytest.mark.parametrize("B,c1,c2,cout,H,W,pad,act", WTHIN)
