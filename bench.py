@@ -396,6 +396,9 @@ def main():
     ap.add_argument("--conv-algo", choices=("winograd", "direct"), default=None,
                     help="fp32 algorithm of the wide 3x3 convolutions (default: the library's, winograd = F(2x2,3x3) on the "
                          "f32 MFMA pipe; direct = implicit GEMM): both are fp32 operands / fp32 accumulation")
+    ap.add_argument("--graph-step", action="store_true",
+                    help="replay the iteration as ONE HIP graph (scm_gan_amd.graph_step.GraphedTrainer: two eager iterations, "
+                         "capture, then replays; single GPU, default loss): what the launch-bound small-batch shapes gain")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--profile-mode", action="store_true",
@@ -412,6 +415,9 @@ def main():
     cfg2 = shape_ok and a.config == 2 and a.batch == 256
     if a.profile_mode:
         a.no_kernel_timer = a.no_cpu_baseline = True
+    if a.graph_step:
+        a.no_kernel_timer = True            # (event brackets cannot be recorded inside a captured graph)
+        a.warmup = max(a.warmup, 4)         # two eager iterations + the capture + one replay before the timed region
 
     from scm_gan_amd import dp
     rank, local_rank, world, under_launcher = dp.env_world()
@@ -444,8 +450,12 @@ def main():
             dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
+    stepper = trainer
+    if a.graph_step:
+        from scm_gan_amd.graph_step import GraphedTrainer
+        stepper = GraphedTrainer(trainer)
     for i in range(a.warmup):
-        trainer.step(*batches[i % 2], theta=0.5, train_iter=i + 1)
+        stepper.step(*batches[i % 2], theta=0.5, train_iter=i + 1)
     # HIP-event brackets around the MFMA conv launches (roofline): recorded on the launch stream inside the timed
     # region, on every 10th step only -- two events per launch stall the queue between kernels: on all steps they cost
     # ~8 % of the step, on every 5th 1.8 %, on every 10th 0.9 %
@@ -456,7 +466,7 @@ def main():
     for i in range(a.steps):
         ops.kernel_timer = timer if i % 10 == 0 else None
         trainer.sync.timing = trainer.sync.enabled and i % 10 == 5       # collective brackets: every 10th step too
-        trainer.step(*batches[i % 2], theta=0.5, train_iter=a.warmup + i + 1)
+        stepper.step(*batches[i % 2], theta=0.5, train_iter=a.warmup + i + 1)
     torch.cuda.synchronize()
     dt_own = time.perf_counter() - t0          # this rank alone, before the closing barrier
     barrier()
@@ -512,6 +522,7 @@ def main():
                                       "(the reference constructs it, models.py:195-223 / main.py:76,128, but defines NO "
                                       "GAN loss: the critic term, the mean logit, is build-defined)"),
                        "global_batch": a.batch * world, "horizon": a.horizon, "parallelism": "dp%d" % world,
+                       "graph_step": bool(a.graph_step),
                        "grad_allreduce": ("none (1 rank)" if world == 1 and not under_launcher else
                                           "RCCL SUM of 4 flat fp32 buckets; decoder/transition/reward-head%s buckets issued "
                                           "from a hook on the first latent's gradient, under the encoder's backward"
