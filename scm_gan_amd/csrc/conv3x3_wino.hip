@@ -182,7 +182,6 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_kernel(const ConvKArgs a)
     float px[KC][NJ][2];    // raw halo pairs of the NEXT chunk (requested a whole iteration ahead)
     float pg[GATED == 1 ? KC : 1][GATED == 1 ? NJ : 1][2];
     unsigned pm[GATED == 2 ? NJ : 1][2];
-    float dd[2][4][4];      // transform scratch: this thread's two 4x4 patches, then their column-transformed form
     float vv[2][16];
 
     auto clampc = [&](int chunk) { return chunk < nchunk ? chunk : nchunk - 1; };
@@ -271,30 +270,46 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_kernel(const ConvKArgs a)
     // (MFMA k index of local channel c: half = c >> 2, step = c & 3)
     // (CW 128: 32 patches x 8 channels = one (patch, channel) item per thread: only CC = 0 is used)
     const int tch = CW == 64 ? 2 * wave : (tid >> 5);         // first local channel of the item
+    // (Packed forms with their operand selects spelled out, as in conv3x3_wgrad_winoz.hip: a patch row arrives as the
+    // column pairs lo = (d0, d1), hi = (d2, d3); along x  (d0 - d2, d1 - d3) = lo - hi  and  (d1 + d2, d2 - d1)  are ONE
+    // v_pk_add_f32 each, along y every step is elementwise on those pairs: 16 VALU instructions per patch instead of
+    // 32 -- each of them is paid for under the f32 MFMAs.)
+    f32x2 dlo[2][4], dhi[2][4];          // this thread's patch rows as loaded, then their x-transformed pairs (0, 3) / (1, 2)
     auto t_rd = [&](auto cc_, auto i_) {
         constexpr int CC = decltype(cc_)::value, I = decltype(i_)::value;
         if constexpr (CW == 128 && CC == 1) return;
         const float* rp = RAW + (tch + CC) * PLANE + traw + I * ROWPL;
-        const f32x2 lo = *reinterpret_cast<const f32x2*>(rp), hi = *reinterpret_cast<const f32x2*>(rp + 2);
-        dd[CC][I][0] = lo[0]; dd[CC][I][1] = lo[1]; dd[CC][I][2] = hi[0]; dd[CC][I][3] = hi[1];
+        dlo[CC][I] = *reinterpret_cast<const f32x2*>(rp);
+        dhi[CC][I] = *reinterpret_cast<const f32x2*>(rp + 2);
     };
     auto t_col = [&](auto cc_, auto i_) {
         constexpr int CC = decltype(cc_)::value, I = decltype(i_)::value;
         if constexpr (CW == 128 && CC == 1) return;
-        const float d0 = dd[CC][I][0], d1 = dd[CC][I][1], d2 = dd[CC][I][2], d3 = dd[CC][I][3];
-        dd[CC][I][0] = d0 - d2;
-        dd[CC][I][1] = d1 + d2;
-        dd[CC][I][2] = d2 - d1;
-        dd[CC][I][3] = d1 - d3;
+        const f32x2 lo = dlo[CC][I], hi = dhi[CC][I];
+        f32x2 p03, p12;
+        asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(p03) : "v"(lo), "v"(hi));                        // (d0 - d2, d1 - d3)
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[1,0]" : "=v"(p12) : "v"(lo), "v"(hi));      // (d1 + d2, d2 - d1)
+        dlo[CC][I] = p03; dhi[CC][I] = p12;
     };
+    // output row J of the position grid (positions 4J .. 4J + 3) from the x-transformed rows
     auto t_row = [&](auto cc_, auto j_) {
         constexpr int CC = decltype(cc_)::value, J = decltype(j_)::value;
         if constexpr (CW == 128 && CC == 1) return;
-        const float c0 = dd[CC][0][J], c1 = dd[CC][1][J], c2 = dd[CC][2][J], c3 = dd[CC][3][J];
-        vv[CC][0 + J] = c0 - c2;
-        vv[CC][4 + J] = c1 + c2;
-        vv[CC][8 + J] = c2 - c1;
-        vv[CC][12 + J] = c1 - c3;
+        f32x2 o03, o12;
+        if constexpr (J == 0) {
+            asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(o03) : "v"(dlo[CC][0]), "v"(dlo[CC][2]));
+            asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(o12) : "v"(dhi[CC][0]), "v"(dhi[CC][2]));
+        } else if constexpr (J == 1) {
+            asm("v_pk_add_f32 %0, %1, %2" : "=v"(o03) : "v"(dlo[CC][1]), "v"(dlo[CC][2]));
+            asm("v_pk_add_f32 %0, %1, %2" : "=v"(o12) : "v"(dhi[CC][1]), "v"(dhi[CC][2]));
+        } else if constexpr (J == 2) {
+            asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(o03) : "v"(dlo[CC][2]), "v"(dlo[CC][1]));
+            asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(o12) : "v"(dhi[CC][2]), "v"(dhi[CC][1]));
+        } else {
+            asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(o03) : "v"(dlo[CC][1]), "v"(dlo[CC][3]));
+            asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(o12) : "v"(dhi[CC][1]), "v"(dhi[CC][3]));
+        }
+        vv[CC][4 * J + 0] = o03[0]; vv[CC][4 * J + 1] = o12[0]; vv[CC][4 * J + 2] = o12[1]; vv[CC][4 * J + 3] = o03[1];
     };
     auto t_vw = [&](int buf, auto f_) {
         constexpr int F = decltype(f_)::value;
