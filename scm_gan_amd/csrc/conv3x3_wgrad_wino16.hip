@@ -89,7 +89,10 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wgrad_wino16_kernel(const Wgra
     const unsigned row_b = (unsigned)W * 4u;
     constexpr int XC = 16 * XT, DC = 16 * DT;        // channels of each side in this workgroup
     constexpr int XP = 36;                            // floats of a staged input row: column x0 - 1 + i at index i
-    constexpr int XSL = 2 * XC * XP, DSL = 2 * DC * 32;        // floats of one slot: [row][channel][column]
+    // (a staged output-gradient row holds 32 columns in DP = 36 floats: with a pitch of 32 the 16 channel lanes of an
+    // operand read sat on two banks -- PMC: LDS bank-conflict cycles 71-75 % of the LDS-active cycles of this kernel)
+    constexpr int DP = 36;
+    constexpr int XSL = 2 * XC * XP, DSL = 2 * DC * DP;        // floats of one slot: [row][channel][column]
     float* const XL = smem;                           // two slots of input rows
     float* const DL = smem + 2 * XSL;                 // two slots of (gated) output-gradient rows
     // scalar bases of this image's channel groups + 32-bit lane offsets (channel plane + column)
@@ -119,7 +122,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wgrad_wino16_kernel(const Wgra
     unsigned sxoff = (unsigned)(cxi - g0x) * (unsigned)plane_b + (unsigned)scol * 4u;
     unsigned sdoff = (unsigned)(cdi - g0d) * (unsigned)plane_b + (unsigned)scol * 4u;
     float* const sxl = XL + (sxr * XC + sxc) * XP + 1 + 4 * sk;     // (+ XC * XP for the second row when XT == 2)
-    float* const sdl = DL + (sdr * DC + sdc) * 32 + 4 * sk;
+    float* const sdl = DL + (sdr * DC + sdc) * DP + 4 * sk;
     const bool hrole = tid < 2 * XC;
     const int hside = tid & 1, hc = (tid >> 1) & (XC - 1);
     int hci = g0x + hc; if (hci > cin - 1) hci = cin - 1;
@@ -130,7 +133,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wgrad_wino16_kernel(const Wgra
     float* const hl = XL + hc * XP + (hside ? 33 : 0);          // (+ XC * XP for the second row)
     // reading lanes: tile channel c, patch pl
     const float* const rxl = XL + c * XP + 2 * pl;
-    const float* const rdl = DL + c * 32 + 2 * pl;
+    const float* const rdl = DL + c * DP + 2 * pl;
 
     f32x4 acc[16][2];
 #pragma unroll
@@ -214,7 +217,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wgrad_wino16_kernel(const Wgra
                 v *= f32x4{g[0] > 0.f ? 1.f : 0.01f, g[1] > 0.f ? 1.f : 0.01f, g[2] > 0.f ? 1.f : 0.01f, g[3] > 0.f ? 1.f : 0.01f};
             }
             csum += (v[0] + v[1]) + (v[2] + v[3]);
-            *reinterpret_cast<f32x4*>(sdl + Q * DSL + i * DC * 32) = v;
+            *reinterpret_cast<f32x4*>(sdl + Q * DSL + i * DC * DP) = v;
         }
     };
     // pair s from LDS slot s & 1 -> the patch's four columns, d B (the transform along x): both steps that use the pair
@@ -244,8 +247,8 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wgrad_wino16_kernel(const Wgra
         float vd[DT][16];
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
-            const float* src = rdl + Q1 * DSL + dt * 16 * 32;
-            const f32x2 d0 = *reinterpret_cast<const f32x2*>(src), d1 = *reinterpret_cast<const f32x2*>(src + DC * 32);
+            const float* src = rdl + Q1 * DSL + dt * 16 * DP;
+            const f32x2 d0 = *reinterpret_cast<const f32x2*>(src), d1 = *reinterpret_cast<const f32x2*>(src + DC * DP);
             const f32x2 rw[4] = {d0, d0 + d1, w16_pk_sub(d0, d1), d1};      // A dY: rows p, p + r, p - r, r
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
