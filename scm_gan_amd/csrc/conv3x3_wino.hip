@@ -58,6 +58,38 @@ __device__ unsigned long long wino_trace[3 * 8192];     // per workgroup: (XCC_I
 // CW: output channels per workgroup.  64: 2 x 2 waves = 64 co x 64 patches (any frame).  128: 4 x 1 waves = 128 co x 32
 // patches -- each transformed patch feeds twice the MFMAs and the raw rows are staged once instead of once per 64-co
 // group; for layers with a multiple of 128 output channels on frames whose patch rows divide 32 (W = 16, 32, 64).
+// packed fp32 forms with their operand selects spelled out (the compiler scalarises them or builds them from moves)
+__device__ __forceinline__ f32x2 wino_pk_add(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f32x2 wino_pk_sub(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f32x2 wino_pk_sumdiff(f32x2 p) {          // (p.x + p.y, p.x - p.y)
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(p));
+    return d;
+}
+__device__ __forceinline__ f32x2 wino_pk_addsub(f32x2 t, f32x2 p) {   // (t.x + p.x, t.y - p.y)
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(d) : "v"(t), "v"(p));
+    return d;
+}
+__device__ __forceinline__ f32x2 wino_pk_fma(f32x2 a, f32x2 b, f32x2 c) {
+    f32x2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ f32x2 wino_pk_mul(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
 template <int NJ, int GATED, int PADC, int CW>
 __global__ void __launch_bounds__(256, 1) conv3x3_wino_kernel(const ConvKArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -146,11 +178,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_kernel(const ConvKArgs a)
         traw = 2 * (ty - ty0) * ROWPL + 2 * tx + 2;
     }
 
-    f32x16 acc[16];
-#pragma unroll
-    for (int f = 0; f < 16; ++f)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+    f32x16 acc[16];          // (first written by chunk 0's MFMAs: slot<FIRST>)
 
     const int cin = a.c1 + a.c2;
     const int nchunk = (cin + KC - 1) / KC;
@@ -343,12 +371,20 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_kernel(const ConvKArgs a)
     //   F = 8, 9       : this thread's patch rows of chunk+1 from RAW (after the mid barrier)
     //   F = 10, 11     : the transform arithmetic
     //   F = 12..15     : V of chunk+1 into the idle stage
-    auto slot = [&](int chunk, int cur, auto f_) {
+    auto slot = [&](int chunk, int cur, auto f_, auto first_) {
         constexpr int F = decltype(f_)::value;
         constexpr int R = F % WINO_UR, Q = F & 1;
+        constexpr bool FIRST = decltype(first_)::value;
         auto mf = [&](auto s_) {
             constexpr int S = decltype(s_)::value;
-            acc[F] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur[R][S], bq[Q][S], acc[F], 0, 0, 0);
+            if constexpr (FIRST && S == 0) {
+                // chunk 0 (peeled in front of the loop): the accumulator operand of a position's first MFMA is the constant
+                // 0 -- 256 v_accvgpr_write of zeros per workgroup (~1 k ticks of an 85 k lifetime) never run
+                const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                acc[F] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur[R][S], bq[Q][S], zero, 0, 0, 0);
+            } else {
+                acc[F] = __builtin_amdgcn_mfma_f32_32x32x2f32(ur[R][S], bq[Q][S], acc[F], 0, 0, 0);
+            }
         };
 #ifndef WINO_ABL
 #define WINO_ABL 0
@@ -433,22 +469,24 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_kernel(const ConvKArgs a)
         __syncthreads();
     }
     WINO_TICK(0);
-    for (int chunk = 0; chunk < nchunk; ++chunk) {
+    auto chunk_body = [&](int chunk, auto first_) {
         const int cur = chunk & 1;
         asm volatile("" : "+v"(uoff[0]), "+v"(uoff[1]), "+v"(uoff[2]), "+v"(uoff[3]));
 #pragma unroll
         for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(poff[j]));
         if (WINO_ABL < 4) b_read(cur, IC(0));
         SB();
-        slot(chunk, cur, IC(0)); slot(chunk, cur, IC(1)); slot(chunk, cur, IC(2)); slot(chunk, cur, IC(3));
-        slot(chunk, cur, IC(4)); slot(chunk, cur, IC(5)); slot(chunk, cur, IC(6)); slot(chunk, cur, IC(7));
+        slot(chunk, cur, IC(0), first_); slot(chunk, cur, IC(1), first_); slot(chunk, cur, IC(2), first_); slot(chunk, cur, IC(3), first_);
+        slot(chunk, cur, IC(4), first_); slot(chunk, cur, IC(5), first_); slot(chunk, cur, IC(6), first_); slot(chunk, cur, IC(7), first_);
         __syncthreads();            // RAW holds chunk+1
         SB();
-        slot(chunk, cur, IC(8)); slot(chunk, cur, IC(9)); slot(chunk, cur, IC(10)); slot(chunk, cur, IC(11));
-        slot(chunk, cur, IC(12)); slot(chunk, cur, IC(13)); slot(chunk, cur, IC(14)); slot(chunk, cur, IC(15));
+        slot(chunk, cur, IC(8), first_); slot(chunk, cur, IC(9), first_); slot(chunk, cur, IC(10), first_); slot(chunk, cur, IC(11), first_);
+        slot(chunk, cur, IC(12), first_); slot(chunk, cur, IC(13), first_); slot(chunk, cur, IC(14), first_); slot(chunk, cur, IC(15), first_);
         __syncthreads();            // V[cur ^ 1] holds chunk+1; every wave is done with V[cur] and RAW
         SB();
-    }
+    };
+    chunk_body(0, std::true_type{});
+    for (int chunk = 1; chunk < nchunk; ++chunk) chunk_body(chunk, std::false_type{});
 #undef IC
 #undef SB
     WINO_TICK(1);
@@ -493,28 +531,38 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_kernel(const ConvKArgs a)
                 }
             }
             unsigned bits[4] = {0u, 0u, 0u, 0u};
+            f32x2 sc2, sl2;
+            sc2[0] = sc; sc2[1] = sc; sl2[0] = slope; sl2[1] = slope;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rowu = (r & 3) + 8 * (r >> 2);
-                float m[16];
+                // A^T M A in packed form (every VALU instruction of a wave is paid for next to its f32 MFMAs):
+                // the 16 positions leave the accumulators as the column pairs (0, 3) and (1, 2) of each grid row -- an
+                // accumulator read can land in any register -- so that the sums along y are elementwise on pairs and the
+                // two outputs of an image row come out of ONE instruction as the pair the 8-byte store takes:
+                //   (o0, o1) = (s0 + (s1 + s2), (s1 - s2) - s3)
+                f32x2 m03[4], m12[4];
 #pragma unroll
-                for (int f = 0; f < 16; ++f) m[f] = acc[f][r];
-                float s0[4], s1[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    s0[j] = m[j] + m[4 + j] + m[8 + j];
-                    s1[j] = m[4 + j] - m[8 + j] - m[12 + j];
+                for (int i = 0; i < 4; ++i) {
+                    m03[i][0] = acc[4 * i][r]; m03[i][1] = acc[4 * i + 3][r];
+                    m12[i][0] = acc[4 * i + 1][r]; m12[i][1] = acc[4 * i + 2][r];
                 }
+                const f32x2 s0_03 = wino_pk_add(wino_pk_add(m03[0], m03[1]), m03[2]);
+                const f32x2 s0_12 = wino_pk_add(wino_pk_add(m12[0], m12[1]), m12[2]);
+                const f32x2 s1_03 = wino_pk_sub(wino_pk_sub(m03[1], m03[2]), m03[3]);
+                const f32x2 s1_12 = wino_pk_sub(wino_pk_sub(m12[1], m12[2]), m12[3]);
+                f32x2 oa = wino_pk_addsub(wino_pk_sumdiff(s0_12), s0_03);       // image row oy:     (o0, o1)
+                f32x2 ob = wino_pk_addsub(wino_pk_sumdiff(s1_12), s1_03);       // image row oy + 1: (o2, o3)
+                f32x2 bb;
+                bb[0] = BIASL[co_l + rowu + 4 * lh]; bb[1] = bb[0];
+                oa = wino_pk_fma(oa, sc2, bb);
+                ob = wino_pk_fma(ob, sc2, bb);
+                const f32x2 la = wino_pk_mul(oa, sl2), lb = wino_pk_mul(ob, sl2);
                 float o[4];
-                o[0] = s0[0] + s0[1] + s0[2];
-                o[1] = s0[1] - s0[2] - s0[3];
-                o[2] = s1[0] + s1[1] + s1[2];
-                o[3] = s1[1] - s1[2] - s1[3];
-                const float badd = BIASL[co_l + rowu + 4 * lh];
+                o[0] = fmaxf(oa[0], la[0]); o[1] = fmaxf(oa[1], la[1]);      // none (slope 1) / leaky_relu (0.01): bitwise scm_act_sel
+                o[2] = fmaxf(ob[0], lb[0]); o[3] = fmaxf(ob[1], lb[1]);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float u = fmaf(o[q], sc, badd);
-                    o[q] = fmaxf(u, slope * u);          // none (slope 1) / leaky_relu (0.01): bitwise scm_act_sel
                     bits[q] |= (o[q] > 0.f ? 1u : 0u) << (rowu + 4 * lh);
                     if constexpr (YG) o[q] = (gw[q] & (1u << rowu)) ? o[q] : 0.01f * o[q];
                     if constexpr (ADD) o[q] += old[r][q];
