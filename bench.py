@@ -399,6 +399,9 @@ def main():
     ap.add_argument("--graph-step", action="store_true",
                     help="replay the iteration as ONE HIP graph (scm_gan_amd.graph_step.GraphedTrainer: two eager iterations, "
                          "capture, then replays; single GPU, default loss): what the launch-bound small-batch shapes gain")
+    ap.add_argument("--no-half-store", action="store_true",
+                    help="with --precision fp16: keep fp32 tensors between the wide layers (default: the maps only the wide "
+                         "16-bit kernels read are stored as IEEE half, ops.set_half_store)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--profile-mode", action="store_true",
@@ -433,6 +436,7 @@ def main():
     from scm_gan_amd import main as M, ops
     from scm_gan_amd.datasource import SyntheticDatasource
     ops.set_compute_precision(a.precision)
+    ops.set_half_store(not a.no_half_store)
     if a.conv_algo:
         ops.set_conv_algo(a.conv_algo)
     opts = M.parser.parse_args(["--train-iters", str(a.steps + a.warmup), "--horizon-min", str(a.horizon),
@@ -522,7 +526,7 @@ def main():
                                       "(the reference constructs it, models.py:195-223 / main.py:76,128, but defines NO "
                                       "GAN loss: the critic term, the mean logit, is build-defined)"),
                        "global_batch": a.batch * world, "horizon": a.horizon, "parallelism": "dp%d" % world,
-                       "graph_step": bool(a.graph_step),
+                       "graph_step": bool(a.graph_step), "half_store": bool(a.precision == "fp16" and not a.no_half_store),
                        "grad_allreduce": ("none (1 rank)" if world == 1 and not under_launcher else
                                           "RCCL SUM of 4 flat fp32 buckets; decoder/transition/reward-head%s buckets issued "
                                           "from a hook on the first latent's gradient, under the encoder's backward"

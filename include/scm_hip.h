@@ -104,6 +104,12 @@ typedef struct scm_conv3x3_desc {
      * gradient that is already gated, and that layer's own gradient kernels run with gate_act = 0 -- the gate is
      * applied once, by the producer's epilogue, instead of twice, by the staging code of both consumers. */
     const uint32_t* gate_mask_y1; const uint32_t* gate_mask_y2;
+    /* scm_conv3x3_h16 only (the other entry points refuse them).  x_half != 0: x1 / x2 point to IEEE-half tensors (same
+     * NCHW shapes), as written by a call with y_half != 0: in the 16-bit operand mode the activations between two
+     * convolutions then cross HBM at two bytes per element -- the operands are rounded to fp16 once either way, when
+     * stored instead of when staged.  Gradient tensors (a call's x1 in the input-gradient direction, its y1 / y2)
+     * stay fp32: y_half requires accumulate_y1 == 0. */
+    int32_t x_half; int32_t y_half;
 } scm_conv3x3_desc;
 
 int scm_conv3x3(const scm_conv3x3_desc* d, void* stream);
@@ -153,6 +159,9 @@ typedef struct scm_conv3x3_wgrad_desc {
                                                (ceil(9*cout*cin/256) floats) for scm_sn_fold_grad */
     const uint32_t* gate_mask;              /* optional 1-bit leaky-relu gate (scm_conv3x3_desc.gate_mask_out of the
                                                forward call, C = cout); `gate` must still be passed */
+    int32_t x_half;                         /* scm_conv3x3_wgrad / scm_conv3x3_wgrad_h16 on the kernels of the 16-bit
+                                               operand mode: x1 / x2 are IEEE-half tensors (scm_conv3x3_desc.y_half);
+                                               refused by the Winograd and split-precision kernels */
 } scm_conv3x3_wgrad_desc;
 
 int scm_conv3x3_wgrad_workspace(int B, int H, int W, int cin, int cout, size_t* part_floats,

@@ -32,6 +32,7 @@ class ConvDesc(ctypes.Structure):
         ("gate_mask_out", ctypes.c_void_p), ("gate_mask_in", ctypes.c_void_p),
         ("accumulate_y1", ctypes.c_int32),
         ("gate_mask_y1", ctypes.c_void_p), ("gate_mask_y2", ctypes.c_void_p),
+        ("x_half", ctypes.c_int32), ("y_half", ctypes.c_int32),
     ]
 
 
@@ -47,6 +48,7 @@ class WgradDesc(ctypes.Structure):
         ("dw_cin_total", ctypes.c_int32), ("dw_ci0", ctypes.c_int32),
         ("dot_w", ctypes.c_void_p), ("dot_part", ctypes.c_void_p),
         ("gate_mask", ctypes.c_void_p),
+        ("x_half", ctypes.c_int32),
     ]
 
 

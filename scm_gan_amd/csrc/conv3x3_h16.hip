@@ -31,6 +31,7 @@
 #define HKC 16
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2h __attribute__((ext_vector_type(2)));
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 b16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
@@ -72,7 +73,8 @@ __device__ unsigned long long h16_ticks[8];
 // WPS: workgroups per CU (= waves per SIMD).  1: 512-pixel tiles, 256 accumulator registers, two LDS stages when they fit.
 // 2: 256-pixel tiles (PT = 2), one LDS stage -- two workgroups share a CU and drift apart, so one's staging, barriers and
 // epilogue (a third of a workgroup's time at 128 -> 128: the whole chip writing at once) run under the other's MFMAs.
-template <int PREC, int CT, int PT, int NJ, int GATED, int WPS = 1>
+// XH: the inputs are IEEE-half tensors (scm_conv3x3_desc.x_half; forward launches of the fp16 precision only)
+template <int PREC, int CT, int PT, int NJ, int GATED, int WPS = 1, int XH = 0>
 __global__ void __launch_bounds__(256, WPS) conv3x3_h16_kernel(const ConvKArgs a) {
     extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
     constexpr int CW = CT * 32;
@@ -182,13 +184,31 @@ __global__ void __launch_bounds__(256, WPS) conv3x3_h16_kernel(const ConvKArgs a
         const u32x4 t = wsrc[gi];
         pw[k][0] = t[0]; pw[k][1] = t[1]; pw[k][2] = t[2]; pw[k][3] = t[3];
     };
+    // x_half: the inputs are IEEE-half tensors (written by a call with y_half): two bytes per element cross HBM; the
+    // value staged is the same fp16 number either way
+    typedef const __attribute__((address_space(1))) _Float16* ghp;
+    constexpr bool xh = XH != 0;
+    ghp hb1 = (ghp)(gfp)(a.x1) + (size_t)b * a.c1 * HW;
+    ghp hb2 = a.c2 ? (ghp)(gfp)(a.x2) + ((size_t)b * a.c2 - a.c1) * HW : hb1;
     auto fetch_x_ch = [&](int ci0, int c) {
         const int ci = ci0 + c;
         const int cc = ci < cin ? ci : 0;
         const bool first = cc < a.c1;
-        const gfp src = (first ? xb1 : xb2) + (size_t)cc * HW;
+        if constexpr (xh) {
+            // two channels share a register (px of the even one): the 2-byte loads land in its low / high half
+            // (global_load_short_d16 / _d16_hi) and the LDS image takes it as it is -- no conversion, no packing
+            const ghp hsrc = (first ? hb1 : hb2) + (size_t)cc * HW;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) px[c][j] = src[goff[j]];
+            for (int j = 0; j < NJ; ++j) {
+                h16x2 t = __builtin_bit_cast(h16x2, px[c & ~1][j]);
+                t[c & 1] = hsrc[goff[j]];
+                px[c & ~1][j] = __builtin_bit_cast(float, t);
+            }
+        } else {
+            const gfp src = (first ? xb1 : xb2) + (size_t)cc * HW;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) px[c][j] = src[goff[j]];
+        }
         if constexpr (GATED == 1) {
             const gfp gsrc = (first ? gb1 : gb2) + (size_t)cc * HW;
 #pragma unroll
@@ -235,6 +255,15 @@ __global__ void __launch_bounds__(256, WPS) conv3x3_h16_kernel(const ConvKArgs a
             const bool ok = (okmask >> j) & 1u;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
+                if constexpr (xh) {
+                    // (channels beyond cin are zero in the weight pack; what is staged for them only has to be finite:
+                    // the loads re-read channel 0)
+                    u32x4 u;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) u[i] = ok ? __float_as_uint(px[8 * h + 2 * i][j]) : 0u;
+                    xl[h * PLANE + tid + 256 * j] = u;
+                    continue;
+                }
                 float v[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
@@ -404,7 +433,19 @@ __global__ void __launch_bounds__(256, WPS) conv3x3_h16_kernel(const ConvKArgs a
             const int p = p0 + wave * NPW + 4 * q4;
 #pragma unroll
             for (int i = 0; i < 4; ++i) bits[i] |= (v[i] > 0.f ? 1u : 0u) << row;
-            if (co < a.cout) {
+            if (co < a.cout && a.y_half) {          // (wave-uniform) the activation leaves as IEEE half: 8-byte lanes
+                _Float16* dst = (co < a.co1 ? reinterpret_cast<_Float16*>(a.y1) + ((size_t)b * a.co1 + co) * HW
+                                            : reinterpret_cast<_Float16*>(a.y2) + ((size_t)b * co2n + (co - a.co1)) * HW) + p;
+                if (vec && p + 3 < HW) {
+                    u32x2h t;
+                    t[0] = pack2<SCM_PREC_F16>(v[0], v[1]); t[1] = pack2<SCM_PREC_F16>(v[2], v[3]);
+                    *reinterpret_cast<u32x2h*>(dst) = t;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (p + i < HW) dst[i] = (_Float16)v[i];
+                }
+            } else if (co < a.cout) {
                 float* dst = (co < a.co1 ? a.y1 + ((size_t)b * a.co1 + co) * HW
                                          : a.y2 + ((size_t)b * co2n + (co - a.co1)) * HW) + p;
                 const bool add = a.acc_y1 && co < a.co1;
@@ -533,6 +574,16 @@ static int launch_h16_nj(const ConvKArgs& a, int groups, hipStream_t s) {
     constexpr size_t lds_main = (WPS == 1 && 2 * stage <= 160 * 1024) ? 2 * stage : stage;
     constexpr size_t lds = (lds_main > ep_bytes ? lds_main : ep_bytes) + CT * 32 * sizeof(float);   // + bias table
     static_assert(lds * WPS <= 160 * 1024, "halo tile exceeds the LDS");
+    if constexpr (PREC == SCM_PREC_F16 && GATED == 0) {
+        if (a.x_half) {
+            auto kernh = conv3x3_h16_kernel<PREC, CT, PT, NJ, GATED, WPS, 1>;
+            static std::atomic<uint64_t> attr_done_h{0};
+            if (int rc = scm_ensure_lds_attr(reinterpret_cast<const void*>(kernh), attr_done_h, 160 * 1024)) return rc;
+            hipLaunchKernelGGL(kernh, dim3(a.B * a.tiles_per_img, groups), dim3(256), lds, s, a);
+            SCM_LAUNCH_CHECK("conv3x3_h16_kernel");
+            return SCM_OK;
+        }
+    }
     auto kern = conv3x3_h16_kernel<PREC, CT, PT, NJ, GATED, WPS>;
     static std::atomic<uint64_t> attr_done{0};       // per (instantiation, device)
     if (int rc = scm_ensure_lds_attr(reinterpret_cast<const void*>(kern), attr_done, 160 * 1024)) return rc;
@@ -610,6 +661,12 @@ extern "C" int scm_conv3x3_h16(const scm_conv3x3_desc* d, int precision, void* s
     k.mask_in = d->gate_mask_in;
     k.mask_out = (d->act == SCM_ACT_LRELU && d->cout > 32) ? d->gate_mask_out : nullptr;
     SCM_REQUIRE(!d->gate_mask_out || k.mask_out, "scm_conv3x3_h16: gate_mask_out needs act == LRELU and cout > 32");
+    k.x_half = d->x_half != 0; k.y_half = d->y_half != 0;
+    SCM_REQUIRE(!k.y_half || !d->accumulate_y1, "scm_conv3x3_h16: y_half and accumulate_y1 exclude each other");
+    SCM_REQUIRE(!k.x_half || (d->gate_act == 0 && precision == SCM_PREC_F16),
+                "scm_conv3x3_h16: x_half takes ungated inputs in the fp16 precision (activations, not gradients)");
+    SCM_REQUIRE(!k.y_half || ((reinterpret_cast<size_t>(d->y1) | reinterpret_cast<size_t>(d->y2)) & 7) == 0,
+                "scm_conv3x3_h16: y_half needs 8-byte aligned outputs");
     hipStream_t s = (hipStream_t)stream;
     return precision == SCM_PREC_F16 ? launch_h16_ct<SCM_PREC_F16>(k, s) : launch_h16_ct<SCM_PREC_BF16>(k, s);
 }

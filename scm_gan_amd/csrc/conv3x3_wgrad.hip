@@ -91,11 +91,19 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN) / 4) conv3x3_wgrad_ker
     // masked afterwards with a select: a load under a per-lane condition makes hipcc
     // branch around each load and serialise them (cdna guide, "three .s-level traps" (c)).
     // wave-uniform base of x channel c of this workgroup's ci range (x1 when beyond cin)
+    // x_half: the activations are IEEE-half tensors (scm_conv3x3_desc.y_half); xbase() then returns the plane's address
+    // counted in HALF elements from a.x1 / a.x2 reinterpreted (same element offsets, two bytes each): ld_x() reads it
+    const bool xh = a.x_half != 0;
     auto xbase = [&](int c, bool& valid) -> const float* {
         const int ci = ci_base + c;
         valid = ci < cin;
         const int cc = valid ? ci : 0;
-        return cc < a.c1 ? a.x1 + ((size_t)b * a.c1 + cc) * HW : a.x2 + ((size_t)b * a.c2 + (cc - a.c1)) * HW;
+        const size_t o = cc < a.c1 ? ((size_t)b * a.c1 + cc) * HW : ((size_t)b * a.c2 + (cc - a.c1)) * HW;
+        const float* base = cc < a.c1 ? a.x1 : a.x2;
+        return xh ? reinterpret_cast<const float*>(reinterpret_cast<const _Float16*>(base) + o) : base + o;
+    };
+    auto ld_x = [&](const float* plane, int idx) -> float {
+        return xh ? (float)reinterpret_cast<const _Float16*>(plane)[idx] : plane[idx];
     };
     // the one halo element of this thread: channel hc, side hs (0: left col, 1: right col)
     const int hc = tid >> 1, hs = tid & 1;
@@ -143,9 +151,9 @@ __global__ void __launch_bounds__(WM * WN * 64, (WM * WN) / 4) conv3x3_wgrad_ker
             for (int k = 0; k < XR; ++k) {
                 bool cv;
                 const float* src = xbase(wave * XR + k, cv);
-                px[k] = src[ro + xi_main];
+                px[k] = ld_x(src, ro + xi_main);
             }
-            phalo = hsrc[ro + xi_halo];
+            phalo = ld_x(hsrc, ro + xi_halo);
         };
         auto store_xrow = [&](int r) {
             const int slot = (r + 4) & 3;
@@ -334,11 +342,19 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wgrad_m16_kernel(const WgradKA
     const float* ap = dyl + (wco * 16 + l15) * DPL + lq;
     const float* bp = xl + (wci * 16 + l15) * XPL + lq;
 
+    // x_half: the activations are IEEE-half tensors (scm_conv3x3_desc.y_half); xbase() then returns the plane's address
+    // counted in HALF elements from a.x1 / a.x2 reinterpreted (same element offsets, two bytes each): ld_x() reads it
+    const bool xh = a.x_half != 0;
     auto xbase = [&](int c, bool& valid) -> const float* {
         const int ci = ci_base + c;
         valid = ci < cin;
         const int cc = valid ? ci : 0;
-        return cc < a.c1 ? a.x1 + ((size_t)b * a.c1 + cc) * HW : a.x2 + ((size_t)b * a.c2 + (cc - a.c1)) * HW;
+        const size_t o = cc < a.c1 ? ((size_t)b * a.c1 + cc) * HW : ((size_t)b * a.c2 + (cc - a.c1)) * HW;
+        const float* base = cc < a.c1 ? a.x1 : a.x2;
+        return xh ? reinterpret_cast<const float*>(reinterpret_cast<const _Float16*>(base) + o) : base + o;
+    };
+    auto ld_x = [&](const float* plane, int idx) -> float {
+        return xh ? (float)reinterpret_cast<const _Float16*>(plane)[idx] : plane[idx];
     };
     const int hc = tid >> 1, hs = tid & 1;       // halo element of this thread (threads 0..255)
     bool hvalid = false;
@@ -382,9 +398,9 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wgrad_m16_kernel(const WgradKA
             for (int k = 0; k < XR; ++k) {
                 bool cv;
                 const float* src = xbase(wave * XR + k, cv);
-                px[k] = src[ro + xi_main];
+                px[k] = ld_x(src, ro + xi_main);
             }
-            phalo = hsrc[ro + xi_halo];
+            phalo = ld_x(hsrc, ro + xi_halo);
         };
         auto store_xrow = [&](int r) {
             const int slot = (r + 3) % 3;
@@ -641,6 +657,13 @@ static int wgrad_impl(const scm_conv3x3_wgrad_desc* d, int precision, void* stre
     a.spi = p.spi; a.rows_per_split = p.rows_per_split; a.nseg = p.nseg; a.PS = p.PS;
     a.ci_groups = p.ci_groups;
     a.gate_mask = d->gate_mask;
+    a.x_half = d->x_half != 0;
+    // IEEE-half activations: read by the 16-bit weight-gradient kernel and the direct 16-channel kernels only
+    const bool h16_wide = precision != SCM_PREC_F32 && precision != SCM_PREC_BF16X3 && precision != SCM_ALGO_WINO &&
+                          d->cout > 64 && p.m16 == 0 && p.mt == 4;
+    SCM_REQUIRE(!a.x_half || h16_wide || (p.m16 && precision != SCM_ALGO_WINO),
+                "scm_conv3x3_wgrad: x_half is taken by the 16-bit weight-gradient kernel (scm_conv3x3_wgrad_h16, more than 64 "
+                "output channels) and the direct 16-channel-side kernels only");
     hipStream_t s = (hipStream_t)stream;
     int rc;
     if (precision == SCM_ALGO_WINO && d->cout >= 48 && cin >= 48 && scm_wgrad_wino_serves(a)) {

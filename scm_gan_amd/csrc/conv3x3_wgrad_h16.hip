@@ -99,6 +99,10 @@ __global__ void __launch_bounds__(256 * WN, 1) conv3x3_wgrad_h16_kernel(const Wg
     const bool xvalid = xci < cin;
     const int xcc = xvalid ? xci : 0;
     const float* xsrc = xcc < a.c1 ? a.x1 + ((size_t)b * a.c1 + xcc) * HW : a.x2 + ((size_t)b * a.c2 + (xcc - a.c1)) * HW;
+    // x_half: the activations are IEEE-half tensors (scm_conv3x3_desc.y_half): same element offsets, two bytes each
+    const bool xh = a.x_half != 0;
+    const _Float16* xsrch = xcc < a.c1 ? reinterpret_cast<const _Float16*>(a.x1) + ((size_t)b * a.c1 + xcc) * HW
+                                       : reinterpret_cast<const _Float16*>(a.x2) + ((size_t)b * a.c2 + (xcc - a.c1)) * HW;
     // dyp: DT tasks per thread: channel dc = (tid >> 3) + DSTEP j, group dg = tid & 7
     const int dg = tid & 7;
     const float* dsrc[DT];
@@ -156,10 +160,44 @@ __global__ void __launch_bounds__(256 * WN, 1) conv3x3_wgrad_h16_kernel(const Wg
         const int xc0 = x0 + 8 * xg;             // first image column of this thread's x group
         const int dc0 = x0 + 8 * dg;
 
+        // the same eight pixels of a half tensor: one 16-byte load (VEC) or eight 2-byte ones
+        auto load8h = [&](const _Float16* row, int c0, float* v) {
+            if constexpr (VEC) {
+                const int cc = c0 + 7 < W ? c0 : W - 8;
+                const h16x8 t = *reinterpret_cast<const h16x8*>(row + cc);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = (float)t[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int c = c0 + i;
+                    v[i] = (float)row[c < W ? c : W - 1];
+                }
+            }
+        };
         auto fetch_x = [&](int r) {              // image row r (may be -1 or H)
             int ri = r;
             if (circ) ri = r < 0 ? r + H : (r >= H ? r - H : r);
             ri = ri < 0 ? 0 : (ri >= H ? H - 1 : ri);
+            if (xh) {
+                const _Float16* row = xsrch + (size_t)ri * W;
+                load8h(row, xc0, px + 1);
+                int cl = xc0 - 1, cr = xc0 + 8;
+                if (circ) {
+                    cl = cl < 0 ? cl + W : cl;
+                    cr = cr >= W ? cr - W : cr;
+                }
+                cl = cl < 0 ? 0 : (cl >= W ? W - 1 : cl);
+                cr = cr >= W ? W - 1 : cr;
+                px[0] = (float)row[cl];
+                px[9] = (float)row[cr];
+                if constexpr (!VEC) {
+                    int ce = x0 + ps;
+                    if (circ) ce = ce >= W ? ce - W : ce;
+                    pe = (float)row[ce < W ? ce : W - 1];
+                }
+                return;
+            }
             const float* row = xsrc + (size_t)ri * W;
             load8(row, xc0, px + 1);
             int cl = xc0 - 1, cr = xc0 + 8;

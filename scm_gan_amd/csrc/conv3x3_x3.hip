@@ -546,6 +546,7 @@ static int x3_tile_geometry(ConvKArgs& k, int NP) {
 
 extern "C" int scm_conv3x3_x3(const scm_conv3x3_desc* d, void* stream) {
     SCM_REQUIRE(d != nullptr, "scm_conv3x3_x3: null descriptor");
+    SCM_REQUIRE(!d->x_half && !d->y_half, "scm_conv3x3_x3: IEEE-half tensors (x_half / y_half) are taken by scm_conv3x3_h16 only");
     SCM_REQUIRE(d->x1 && d->c1 > 0, "scm_conv3x3_x3: x1/c1 required");
     SCM_REQUIRE((d->x2 != nullptr) == (d->c2 > 0) && d->c2 >= 0, "scm_conv3x3_x3: x2/c2 mismatch");
     SCM_REQUIRE(d->wpack && d->cout > 0, "scm_conv3x3_x3: wpack/cout required");

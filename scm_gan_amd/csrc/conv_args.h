@@ -17,6 +17,7 @@ struct ConvKArgs {
     const unsigned* mask_in; unsigned* mask_out;   // 1-bit leaky-relu gate, words [B][ceil(C/32)][HW] (scm_hip.h)
     int acc_y1;                                    // y1 += result (a second consumer's input gradient lands in the same buffer)
     const unsigned* ymask1; const unsigned* ymask2; // conv3x3_wino.hip: leaky-relu gates applied to what is written to y1 / y2 (scm_hip.h)
+    int x_half = 0, y_half = 0;                    // conv3x3_h16.hip: x1 / x2 (y1 / y2) are IEEE-half tensors (scm_hip.h)
 };
 
 

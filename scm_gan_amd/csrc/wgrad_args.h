@@ -11,6 +11,7 @@ struct WgradKArgs {
     int spi; int rows_per_split; int nseg; int PS;
     int ci_groups;
     const unsigned* gate_mask;     // 1-bit leaky-relu gate, words [B][ceil(cout/32)][HW], or null
+    int x_half = 0;                // x1 / x2 are IEEE-half tensors (conv3x3_wgrad_h16.hip, the direct 16-channel kernels)
 };
 
 // Workgroup -> (split, channel group) for grids of (B * spi splits, groups): the groups of one split read the same rows

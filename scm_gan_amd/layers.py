@@ -55,7 +55,7 @@ class Conv2d(nn.Module):
         return self._packs
 
     def forward(self, x, x2=None, act_vec=None, act=ops.ACT_NONE, _sn=None, dx1_cell=None, dx2_cell=None,
-                in_masks=None, pregated=False, mask_holder=None):
+                in_masks=None, pregated=False, mask_holder=None, out_half=False, out_cell=None):
         """x (and optionally x2, concatenated along channels without being
         materialised); act_vec: (B, A) values of A trailing constant input planes
         (circular 3x3 only).  _sn = (weight_bar, u, v, inv_sigma) from SpectralNorm.
@@ -73,7 +73,10 @@ class Conv2d(nn.Module):
                 raise ValueError("constant action planes fold into a bias only under circular padding")
             cfg = {"pad": ops.PAD_CIRCULAR if self.padding_mode == "circular" else ops.PAD_ZERO, "act": act,
                    "transposed": False, "packs": self._get_packs(w, cin_conv), "dx1_cell": dx1_cell, "dx2_cell": dx2_cell,
-                   "in_masks": in_masks, "pregated": pregated, "mask_holder": mask_holder}
+                   "in_masks": in_masks, "pregated": pregated, "mask_holder": mask_holder,
+                   # 16-bit operand mode: the output leaves as IEEE half and its fp32 gradient comes back through
+                   # out_cell (the dx1_cell / dx2_cell of its consumers): ops.half_store_ok
+                   "out_half": out_half, "out_cell": out_cell}
             return ops.Conv3x3Fn.apply(x, x2, act_vec, w, self.bias, inv_sigma, u, v, cfg)
         if x2 is not None or act_vec is not None:
             raise ValueError("two-input / action-plane forms need the 3x3 same-size geometry")

@@ -71,6 +71,23 @@ class Transition(nn.Module):
               and os.environ.get("SCM_NO_SHARED_GRAD", "0") in ("", "0"))
         m1, m2, m3, m4, m5 = ({} if pg else None for _ in range(5))
         mk = (lambda h: h["mask"]) if pg else (lambda h: None)
+        if not return_all and ops.half_store_ok():
+            # 16-bit operand mode (training path and rollouts; not when the caller receives the maps): skip2, out3 and
+            # out4 -- the maps that only the wide 16-bit kernels read -- cross HBM as IEEE half (ops.half_store_ok); their
+            # fp32 gradients come back through one cell per map, into which every consumer's input-gradient convolution
+            # writes / accumulates.  skip1 and out5 stay fp32: conv6's thin kernels (16 output channels: forward and the
+            # direct weight gradient) read one element per lane and channel and are SLOWER on 2-byte loads (measured).
+            g2, g3, g4 = ({} for _ in range(3))
+            skip1 = self.conv1(s, None, a, act=L)
+            fork = torch.is_grad_enabled() and skip1.requires_grad
+            c1 = {} if fork else None
+            s1a, s1b = ops.SharedGradFork.apply(skip1, c1) if fork else (skip1, skip1)
+            skip2 = self.conv2(s1a, act=L, dx1_cell=c1, out_half=True, out_cell=g2)
+            out3 = self.conv3(skip2, act=L, dx1_cell=g2, out_half=True, out_cell=g3)
+            out4 = self.conv4(out3, act=L, dx1_cell=g3, out_half=True, out_cell=g4)
+            out5 = self.conv5(out4, skip2, act=L, dx1_cell=g4, dx2_cell=g2)
+            p = self.conv6(out5, s1b, act=ops.ACT_SIGMOID, dx2_cell=c1)
+            return self._sample(p)
         # the action planes (models.py:68-73) enter conv1 as a per-sample bias
         skip1 = self.conv1(s, None, a, act=L, pregated=pg, mask_holder=m1)
         if torch.is_grad_enabled() and skip1.requires_grad and os.environ.get("SCM_NO_SHARED_GRAD", "0") in ("", "0"):
@@ -91,17 +108,20 @@ class Transition(nn.Module):
             out4 = self.conv4(out3, act=L)
             out5 = self.conv5(out4, skip2, act=L)
             p = self.conv6(out5, skip1, act=ops.ACT_SIGMOID)
-        if self.training:
-            if self._noise_queue:
-                x = ops.BernoulliSTFn.apply(p, self._noise_queue.pop(0), 1, 0, 0)
-            else:
-                x = ops.BernoulliSTFn.apply(p, None, 2, self.noise_seed, self._noise_offset)
-                self._noise_offset += (p.numel() + 3) // 4
-        else:
-            x = ops.threshold(p)
+        x = self._sample(p)
         if return_all:
             return (skip1, skip2, out3, out4, out5, x)
         return x
+
+    def _sample(self, p):
+        """models.py:104-113: Bernoulli straight-through sample in training, threshold in eval."""
+        if self.training:
+            if self._noise_queue:
+                return ops.BernoulliSTFn.apply(p, self._noise_queue.pop(0), 1, 0, 0)
+            x = ops.BernoulliSTFn.apply(p, None, 2, self.noise_seed, self._noise_offset)
+            self._noise_offset += (p.numel() + 3) // 4
+            return x
+        return ops.threshold(p)
 
 
 class Encoder(nn.Module):
@@ -121,6 +141,14 @@ class Encoder(nn.Module):
     def forward(self, x):
         batch_size, frames, channels, height, width = x.shape
         x = x.reshape(batch_size, frames * channels, height, width)
+        if ops.half_store_ok():
+            # 16-bit operand mode: the two hidden maps between wide layers as IEEE half, gradients through cells (as in
+            # Transition); conv3's output feeds the 16-channel conv4 and stays fp32
+            g1, g2 = {}, {}
+            x = self.conv1(x, act=ops.ACT_LRELU, out_half=True, out_cell=g1)
+            x = self.conv2(x, act=ops.ACT_LRELU, dx1_cell=g1, out_half=True, out_cell=g2)
+            x = self.conv3(x, act=ops.ACT_LRELU, dx1_cell=g2)
+            return self.conv4(x, act=ops.ACT_SIGMOID)
         pg = torch.is_grad_enabled() and ops.pregate_ok(height, width)       # producer-side gating, as in Transition
         m1, m2, m3 = ({} if pg else None for _ in range(3))
         mk = (lambda h: h["mask"]) if pg else (lambda h: None)

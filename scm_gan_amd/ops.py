@@ -39,10 +39,10 @@ def _dev(name):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
-def _chk(t, name):
+def _chk(t, name, half_ok=False):
     if t is None:
         return None
-    if not t.is_cuda or t.dtype != torch.float32:
+    if not t.is_cuda or (t.dtype != torch.float32 and not (half_ok and t.dtype == torch.float16)):
         raise RuntimeError("scm_gan_amd.%s: expected an fp32 tensor on the GPU (got %s on %s); "
                            "there is no CPU fallback" % (name, t.dtype, t.device))
     return t.contiguous()
@@ -81,6 +81,28 @@ _precision = ["fp32"]
 
 def compute_precision():
     return _precision[0]
+
+
+# In the 16-bit operand mode the leaky-relu maps that only the WIDE 16-bit kernels read -- the transition's skip2, out3,
+# out4, the encoder's first two hidden maps -- are STORED as IEEE half (scm_conv3x3_desc.y_half / x_half): the next layer
+# and the weight gradient read two bytes per element, the value is the fp16 number the MFMA would have been fed anyway
+# (forward bitwise unchanged), the activations saved for the backward pass take half the memory.  Gradients stay fp32 and
+# travel beside the activations in cells (autograd would cast a gradient to its tensor's dtype): models.Transition /
+# Encoder decide per call (half_store_ok).  Measured on one MI355X: the 128 -> 128 forward moves 184 MB
+# instead of 353 MB per launch and takes 104 instead of 120 us; the maps that feed the 16-channel layers (skip1, out5,
+# the encoder's third map) stay fp32 -- those kernels stage one element per lane and channel and were 40-55 % SLOWER on
+# 2-byte loads.  +1.2 % (64x64) / +2.3 % (128x128x4, h = 20) end to end.  SCM_NO_HALF_STORE=1 / set_half_store(False):
+# fp32 tensors everywhere.
+use_half_store = os.environ.get("SCM_NO_HALF_STORE", "0") in ("", "0")
+
+
+def set_half_store(on):
+    global use_half_store
+    use_half_store = bool(on)
+
+
+def half_store_ok():
+    return use_half_store and _precision[0] == "fp16" and use_gate_mask
 
 
 def set_compute_precision(name):
@@ -278,18 +300,24 @@ use_gate_mask = os.environ.get("SCM_NO_GATE_MASK", "0") in ("", "0")
 
 
 def _conv3x3_raw(x1, x2, gate1, gate2, gate_act, wpack, cout, scale, bias, sbias, co1, pad, act, prec=0,
-                 mask_out=None, mask_in=None, y1_acc=None, ymask1=None, ymask2=None):
+                 mask_out=None, mask_in=None, y1_acc=None, ymask1=None, ymask2=None, y_half=False):
     """y1_acc: an existing (B, co1, H, W) tensor the first co1 output channels are ADDED to (accumulate_y1).
     ymask1 / ymask2: leaky-relu gate masks of the activations whose gradients y1 / y2 are (gate_mask_y1 / _y2:
     the Winograd kernel multiplies what it writes by the slope of its own element)."""
     lib = L.lib()
     B, c1, H, W = x1.shape
     c2 = 0 if x2 is None else x2.shape[1]
-    y1 = _new(x1, B, co1, H, W) if y1_acc is None else y1_acc
-    y2 = _new(x1, B, cout - co1, H, W) if co1 < cout else None
+    x_half = x1.dtype == torch.float16
+    if x_half or y_half:
+        if prec != PREC_F16 or (x2 is not None and x2.dtype != x1.dtype) or (y_half and y1_acc is not None):
+            raise RuntimeError("scm_gan_amd.conv3x3: half-stored activations are read / written by the fp16 forward "
+                               "convolution only")
+    ydt = torch.float16 if y_half else torch.float32
+    y1 = torch.empty((B, co1, H, W), device=x1.device, dtype=ydt) if y1_acc is None else y1_acc
+    y2 = torch.empty((B, cout - co1, H, W), device=x1.device, dtype=ydt) if co1 < cout else None
     d = L.ConvDesc(_p(x1), _p(x2), c1, c2, _p(gate1), _p(gate2), gate_act, _p(wpack), cout, _p(scale), _p(bias),
                    _p(sbias), _p(y1), _p(y2), co1, B, H, W, pad, act, _p(mask_out), _p(mask_in),
-                   0 if y1_acc is None else 1, _p(ymask1), _p(ymask2))
+                   0 if y1_acc is None else 1, _p(ymask1), _p(ymask2), int(x_half), int(y_half))
     if kernel_timer is not None:
         ev = kernel_timer.bracket(conv_kernel_name(cout, prec, c1 + c2), 2.0 * B * H * W * cout * (c1 + c2) * 9)
         ev[0].record()
@@ -416,12 +444,16 @@ class Conv3x3Fn(Function):
     @staticmethod
     def forward(ctx, x1, x2, act_vec, weight, bias, inv_sigma, u, v, cfg):
         lib = L.lib()
-        x1 = _chk(x1, "conv3x3")
-        x2 = _chk(x2, "conv3x3")
+        x1 = _chk(x1, "conv3x3", half_ok=True)
+        x2 = _chk(x2, "conv3x3", half_ok=True)
         act_vec = _chk(act_vec, "conv3x3")
         w = _chk(weight.detach(), "conv3x3")
         B, c1, H, W = x1.shape
         c2 = 0 if x2 is None else x2.shape[1]
+        if cfg.get("out_cell") is not None:
+            # this layer's output is a half tensor: its fp32 gradient arrives through the cell, not through autograd
+            # (which would cast it to half); the consumers return None for it
+            ctx.set_materialize_grads(False)
         cout = w.shape[1] if cfg["transposed"] else w.shape[0]
         cin_total = w.shape[0] if cfg["transposed"] else w.shape[1]
         fpack, dpack, fprec, dprec = cfg["packs"][:4]
@@ -449,7 +481,9 @@ class Conv3x3Fn(Function):
         if use_gate_mask and cfg["act"] == ACT_LRELU and cout > 32:
             mask = torch.empty((B, (cout + 31) // 32, H, W), device=x1.device, dtype=torch.int32)
         y, _ = _conv3x3_raw(x1, x2, None, None, 0, fpack, cout, inv_sigma, bias, sbias, cout, cfg["pad"], cfg["act"],
-                            fprec, mask_out=mask)
+                            fprec, mask_out=mask, y_half=bool(cfg.get("out_half")))
+        if cfg.get("out_half") and torch.is_grad_enabled() and (mask is None or cfg.get("out_cell") is None):
+            raise RuntimeError("scm_gan_amd.conv3x3: a half-stored output needs its 1-bit gate and a gradient cell")
         if cfg.get("mask_holder") is not None:
             cfg["mask_holder"]["mask"] = mask          # for the consumers of y (producer-side gating)
         ctx.cfg = cfg
@@ -467,7 +501,15 @@ class Conv3x3Fn(Function):
         x1, x2, act_vec, w, inv_sigma, u, v, y, dpack = ctx.saved_tensors
         cfg = ctx.cfg
         B, c1, c2, H, W, cout, cin_total = ctx.shape
+        if cfg.get("out_cell") is not None:
+            gy = cfg["out_cell"].pop("buf", None)        # (left there by the consumers' backward passes)
+            if gy is None:
+                raise RuntimeError("scm_gan_amd.conv3x3.backward: no gradient was left in the cell of a half-stored "
+                                   "activation (its consumers must be convolutions given dx1_cell / dx2_cell)")
         gy = _chk(gy, "conv3x3.backward")
+        half_y = y.dtype == torch.float16
+        gate_t = gy if half_y else y        # (a half y is never read as a gate: its 1-bit mask is; the pointer must be valid)
+        half_x1, half_x2 = x1.dtype == torch.float16, (x2 is not None and x2.dtype == torch.float16)
         act = cfg["act"]
         gmask = ctx.mask
         if cfg.get("pregated"):
@@ -492,15 +534,17 @@ class Conv3x3Fn(Function):
                 # input gradient left the Winograd kernel (a latent_size below its channel minimum, an oddly offset
                 # gradient view): the direct kernel writes the ungated gradient and the destination's slopes are applied
                 # from its 1-bit mask here, before anything is added to a shared buffer -- rare, correct, not fast.
-                dx1, dx2 = _conv3x3_raw(gy, None, y if act else None, None, act, dpack, c1 + c2, inv_sigma, None, None,
+                dx1, dx2 = _conv3x3_raw(gy, None, gate_t if act else None, None, act, dpack, c1 + c2, inv_sigma, None, None,
                                         c1, cfg["pad"], ACT_NONE, dprec, mask_in=gmask)
                 dx1, dx2 = _gate_by_mask(dx1, in_masks[0]), _gate_by_mask(dx2, in_masks[1])
                 if acc1 is not None:
                     dx1 = acc1.add_(dx1)
             else:
-                dx1, dx2 = _conv3x3_raw(gy, None, y if act else None, None, act, dpack, c1 + c2, inv_sigma, None, None, c1,
+                dx1, dx2 = _conv3x3_raw(gy, None, gate_t if act else None, None, act, dpack, c1 + c2, inv_sigma, None, None, c1,
                                         cfg["pad"], ACT_NONE, dprec, mask_in=gmask, y1_acc=acc1, ymask1=in_masks[0],
                                         ymask2=in_masks[1])
+            if (half_x1 and cell1 is None) or (half_x2 and cell2 is None):
+                raise RuntimeError("scm_gan_amd.conv3x3.backward: a half-stored input needs a gradient cell")
             if cell1 is not None:
                 cell1["buf"] = dx1
             if cell2 is not None and dx2 is not None:
@@ -528,9 +572,10 @@ class Conv3x3Fn(Function):
             dot_part = None
             if inv_sigma is not None and not has_act:
                 dot_part = _new(gy, (9 * cout * (c1 + c2) + 255) // 256)
-            d = L.WgradDesc(_p(x1), _p(x2), c1, c2, _p(gy), _p(y) if act else None, act, cout, _p(dw_eff), _p(db),
+            d = L.WgradDesc(_p(x1), _p(x2), c1, c2, _p(gy), _p(gate_t) if act else None, act, cout, _p(dw_eff), _p(db),
                             _p(csum), _p(part), _p(cws), B, H, W, cfg["pad"], int(cfg["transposed"]), acc_flag,
-                            cin_total, 0, _p(w) if dot_part is not None else None, _p(dot_part), _p(gmask))
+                            cin_total, 0, _p(w) if dot_part is not None else None, _p(dot_part), _p(gmask),
+                            int(half_x1))
             wprec = ctx.dprec if ctx.dprec in (PREC_F16, PREC_BF16) else PREC_F32
             if compute_precision() == "fp32x3":
                 # the split kernel takes 128-wide weight gradients of layers with more than 16 input channels (at any batch:
@@ -558,8 +603,9 @@ class Conv3x3Fn(Function):
                 dw = None                # already accumulated into weight.grad
             if b_sink is not None:
                 db = None
-        return (dx1 if need_x1 else None, dx2 if need_x2 else None, d_act if need_a else None,
-                dw if need_w else None, db if need_b else None, None, None, None, None)
+        # (the gradient of a half-stored input stays in its cell: its producer's backward takes it from there)
+        return (dx1 if (need_x1 and not half_x1) else None, dx2 if (need_x2 and not half_x2) else None,
+                d_act if need_a else None, dw if need_w else None, db if need_b else None, None, None, None, None)
 
 
 class SharedGradFork(Function):

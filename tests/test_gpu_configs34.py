@@ -87,7 +87,8 @@ def _logit(p):
     return torch.log(p) - torch.log1p(-p)
 
 
-def test_cfg5_fp16_mode_vs_oracle_teacher_forced(capsys):
+@pytest.mark.parametrize("half_store", [False, True], ids=["fp32_tensors", "half_stored_activations"])
+def test_cfg5_fp16_mode_vs_oracle_teacher_forced(capsys, half_store):
     """128x128x4 frames, A = 4, R = 2, horizon 20, 16-bit MFMA operands.  The fp32 ORACLE
     runs the training-mode rollout (recorded Bernoulli noise); at every step the HIP modules in the 16-bit mode get
     the oracle's z_t (teacher forcing) and must give: transition logits within 1e-2, a latent flip-rate < 1e-3,
@@ -104,6 +105,7 @@ def test_cfg5_fp16_mode_vs_oracle_teacher_forced(capsys):
     states = states_for(seed, C, A, R)
     oenc, otr, odec, orp = (O.clone_state(st) for st in states)
     ops.set_compute_precision("fp16")
+    ops.set_half_store(half_store)          # (the hidden maps as IEEE half in HBM: same fp16 operands, same results)
     try:
         enc, tr, dec, rp = hip_nets(states, C, A, R)
         # (SpectralNorm advances u / v on every forward: the free-running rollout gets its own transition replica, so
@@ -148,11 +150,12 @@ def test_cfg5_fp16_mode_vs_oracle_teacher_forced(capsys):
                 z_free = tr_free(z_free, up(onehot.numpy()))
                 oz = ozn
         with capsys.disabled():
-            print("\n[cfg5 fp16 vs oracle, 128x128x4, h=20, teacher-forced] max |dlogit| %.2e, max flip-rate/step %.2e, "
+            print("\n[cfg5 fp16 vs oracle, 128x128x4, h=20, teacher-forced, half_store=%s] max |dlogit| %.2e, max flip-rate/step %.2e, "
                   "max decoder-logit err %.2e; free-running per-pixel L1 per step: first %.2e last %.2e max %.2e"
-                  % (max(logit_err), max(flips), max(dec_err), free_l1[0], free_l1[-1], max(free_l1)))
+                  % (half_store, max(logit_err), max(flips), max(dec_err), free_l1[0], free_l1[-1], max(free_l1)))
     finally:
         ops.set_compute_precision("fp32")
+        ops.set_half_store(True)
 
 
 def test_excitation_bptt_64x64_ten_steps_vs_oracle():

@@ -218,3 +218,45 @@ def test_cfg5_shape_step_fp16(fp16_mode):
     assert abs(l16 - l32) / abs(l32) < 2e-2, (l16, l32)
     # Adam's first step moves every weight by ~lr * sign(g): the two modes agree wherever the gradient sign does
     assert float((w16 - w32).abs().max()) < 3e-3
+
+
+def test_half_stored_activations_equal_fp32_tensors(fp16_mode):
+    """16-bit operand mode: with the hidden maps of the encoder / transition STORED as IEEE half (ops.half_store_ok:
+    y_half / x_half of scm_conv3x3_h16, gradients through cells) the forward is bitwise the one over fp32 tensors --
+    the operands were rounded to fp16 once either way -- and the gradients agree to the double rounding of the
+    weight gradient's bf16 operands (bf16(fp16(x)) vs bf16(x)); the half tensors really are what crosses HBM."""
+    from scm_gan_amd import main as T, models as M, ops
+    from scm_gan_amd.datasource import SyntheticDatasource
+
+    def run(half):
+        ops.set_half_store(half)
+        torch.manual_seed(5)
+        enc, dec, rp, disc, tr = M.Encoder(16, 3), M.Decoder(16, 3), M.RewardPredictor(16, 2), M.Discriminator(), \
+            M.Transition(16, 5)
+        tr.seed_noise(11)
+        seen = []
+        hooks = [m.register_forward_hook(lambda mod, i, o: seen.append(o.dtype)) for m in (tr.conv2, tr.conv5, tr.conv6, enc.conv2)]
+        opts = T.parser.parse_args(["--horizon-min", "5", "--horizon-max", "5", "--batch-size", "4"])
+        trainer = T.Trainer(16, 5, 2, enc, dec, rp, disc, tr, opts)
+        ds = SyntheticDatasource(seed=8, height=32, width=32, channels=3, num_actions=5, num_rewards=2, done_every=3)
+        s, r, d, a = ds.get_trajectories(4, 5)[:4]
+        loss = trainer.step(torch.as_tensor(s, dtype=torch.float32).cuda(), torch.as_tensor(r, dtype=torch.float32).cuda(),
+                            torch.as_tensor(d.astype(np.float32)).cuda(), T.onehot(a, 5), theta=0.5, train_iter=1)
+        for h in hooks:
+            h.remove()
+        grads = {n + "." + k: p.grad.detach().clone() for n, m in (("enc", enc), ("tr", tr), ("dec", dec), ("rp", rp))
+                 for k, p in m.named_parameters() if p.grad is not None}
+        return float(loss), grads, seen
+
+    try:
+        l_h, g_h, dt_h = run(True)
+        l_f, g_f, dt_f = run(False)
+    finally:
+        ops.set_half_store(True)
+    assert torch.float16 in dt_h and torch.float32 in dt_h          # conv2 / enc.conv2 half; conv5 / conv6 fp32
+    assert set(dt_f) == {torch.float32}
+    assert l_h == l_f                                               # the forward is bitwise the same
+    assert g_h.keys() == g_f.keys()
+    for k in g_f:
+        den = float(g_f[k].norm()) + 1e-12
+        assert float((g_h[k] - g_f[k]).norm()) / den < 2e-3, k

@@ -93,3 +93,15 @@ zr = (torch.rand(B, 16, H, W, device='cuda') < 0.5).float().requires_grad_(True)
 for _ in range(3):
     rp(zr).sum().backward()
 torch.cuda.synchronize()
+# the 16-bit operand mode with the activations STORED as IEEE half (scm_conv3x3_desc.x_half / y_half; opt-in,
+# ops.set_half_store): forward 128 -> 128 reading and writing half tensors, weight gradient reading a half x
+ops.set_compute_precision('fp16')
+fph, dph, fprech, dprech = ops.pack_conv3x3(w, C, C)[:4]
+xh16 = x.half()
+for _ in range(3):
+    yh, _ = ops._conv3x3_raw(xh16, None, None, None, 0, fph, C, None, bias, None, C, 1, ops.ACT_LRELU, fprech, mask_out=mask, y_half=True)
+    dh = L.WgradDesc(P(xh16), None, C, 0, P(gy), P(gy), ops.ACT_LRELU, C, P(dw), P(db), None, P(part), P(cws), B, H, W, 1, 0, 0, 0, 0,
+                     None, None, P(mask), 1)
+    L.check(lib.scm_conv3x3_wgrad_h16(ctypes.byref(dh), dprech, S()), 'wgrad_h16 half x')
+torch.cuda.synchronize()
+ops.set_compute_precision('fp32')
