@@ -276,6 +276,9 @@ def measured_pmc(kernel_substr, source_file, need="hbm_traffic_bytes"):
     return None
 
 
+HALF_STORE = False          # set in main(): the 16-bit mode with half-stored activations (its forward is the XH = 1 instantiation)
+
+
 def measured_traffic(kernel_name):
     """HBM bytes per launch of the dominant kernel from the newest committed PMC pass
     (profiles/round*_pmc*.json, written by tools/pmc_parse.py).  The number is only valid for
@@ -286,7 +289,7 @@ def measured_traffic(kernel_name):
                                                ("wino" if "wino" in kernel_name else "mfma"))
     src = {"h16": "conv3x3_h16.hip", "x3": "conv3x3_x3.hip", "mfma": "conv3x3_mfma.hip", "wino": "conv3x3_wino.hip"}[kind]
     sha = _sha16(os.path.join(ROOT, "scm_gan_amd", "csrc", src))
-    want = {"h16": "conv3x3_h16_kernel<1,", "x3": "conv3x3_x3_kernel<2, 2, 0,", "mfma": "conv3x3_mfma_kernel<4, 2, 2, 0,",
+    want = {"h16": "conv3x3_h16_kernel<1, 4, 2, 2, 0, 2, 1>" if HALF_STORE else "conv3x3_h16_kernel<1,", "x3": "conv3x3_x3_kernel<2, 2, 0,", "mfma": "conv3x3_mfma_kernel<4, 2, 2, 0,",
             "wino": "conv3x3_wino_kernel<1, 0, 1, 128>"}[kind]
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_pmc*.json")), reverse=True):
         try:
@@ -437,6 +440,8 @@ def main():
     from scm_gan_amd.datasource import SyntheticDatasource
     ops.set_compute_precision(a.precision)
     ops.set_half_store(not a.no_half_store)
+    global HALF_STORE
+    HALF_STORE = a.precision == "fp16" and not a.no_half_store
     if a.conv_algo:
         ops.set_conv_algo(a.conv_algo)
     opts = M.parser.parse_args(["--train-iters", str(a.steps + a.warmup), "--horizon-min", str(a.horizon),
