@@ -581,7 +581,15 @@ class Conv3x3Fn(Function):
                 # the split kernel takes 128-wide weight gradients of layers with more than 16 input channels (at any batch:
                 # its work split fills the chip also where the forward's 512-pixel tiles do not)
                 wprec = PREC_BF16X3 if (W >= 8 and x3_serves(H, W) and cout > 64 and c1 + c2 > 16) else PREC_F32
-            if wprec:
+            thin16 = (cout <= 16 or c1 + c2 <= 16) and not half_x1 and not half_y and _conv_algo[0] == "winograd"
+            if wprec in (PREC_F16, PREC_BF16) and thin16 and gmask is not None:
+                d.gate_mask = None          # (the thin Winograd form takes the float gate: y is an fp32 tensor here)
+            if wprec in (PREC_F16, PREC_BF16) and thin16:
+                # 16-bit mode, a layer with at most 16 channels on one side (Transition.conv6 / conv1, Encoder.conv4 /
+                # conv1): the 16-bit weight-gradient kernel does not take it and the direct fp32 kernel it falls back to is
+                # slower than the fp32 Winograd form of the same gradient (conv6: 184 vs 130 us) -- also the more accurate one
+                L.check(lib.scm_conv3x3_wgrad_wino(ctypes.byref(d), _stream()), "scm_conv3x3_wgrad_wino")
+            elif wprec:
                 L.check(lib.scm_conv3x3_wgrad_h16(ctypes.byref(d), wprec, _stream()), "scm_conv3x3_wgrad_h16")
             elif _conv_algo[0] == "winograd" and compute_precision() == "fp32":
                 # (takes the wide layers, forwards the rest to the direct kernels itself)
