@@ -614,6 +614,12 @@ static int launch_h16(const ConvKArgs& k, int groups, hipStream_t s) {
         // 128 output channels: two 256-pixel workgroups per CU (see WPS) when the halo tile fits two slots per thread
         h16_tile_geometry(a, 256);
         if (a.plane <= 2 * 256 && !getenv("SCM_H16_ONE_WG")) return launch_h16_g<PREC, CT, 2, 2, 2>(a, groups, s);
+        // (128-wide frames -- BASELINE configs[4]: two rows of 128 pixels + halo = 520 elements: three slots per thread)
+        // -- ungated and mask-gated launches only: the float-gated form spills 41 registers at two workgroups per CU
+        if (a.plane <= 3 * 256 && !getenv("SCM_H16_ONE_WG")) {
+            if (a.gate_act == 0) return launch_h16_nj<PREC, CT, 2, 3, 0, 2>(a, groups, s);
+            if (a.mask_in && a.gate_act == SCM_ACT_LRELU && a.c2 == 0) return launch_h16_nj<PREC, CT, 2, 3, 2, 2>(a, groups, s);
+        }
     }
     h16_tile_geometry(a, 512);
     if (a.plane <= 3 * 256) return launch_h16_g<PREC, CT, 4, 3, 1>(a, groups, s);
