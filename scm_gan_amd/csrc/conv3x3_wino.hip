@@ -884,9 +884,11 @@ extern "C" int scm_conv3x3_wino(const scm_conv3x3_desc* d, void* stream) {
     // 128-channel groups, one output tensor per group and the patch rows tile 32 patches
     static const int no128 = getenv("SCM_WINO_NO128") ? atoi(getenv("SCM_WINO_NO128")) : 0;
     const int tcw = d->W / 2;
-    // (one raw pixel pair per thread: the halo rows of 32 patches must fit 512 floats per channel -- W = 2 with H > 62 does not)
-    const bool cw128 = !no128 && (d->cout & 127) == 0 && (d->co1 & 31) == 0 && tcw <= 32 && 32 % tcw == 0 && ntiles % 32 == 0 &&
-                       wino_plane(d->H, d->W, 32) <= 512;
+    // (one raw pixel pair per thread up to 512 floats per channel, two up to 1 024: W = 2 with H > 126 fits neither)
+    // (32 consecutive patches are whole patch rows -- W = 16, 32, 64 -- or an aligned part of one: W = 128, 192, ...;
+    // their raw rows take one or two pixel pairs per thread)
+    const bool cw128 = !no128 && (d->cout & 127) == 0 && (d->co1 & 31) == 0 && ntiles % 32 == 0 &&
+                       ((tcw <= 32 && 32 % tcw == 0) || tcw % 32 == 0) && wino_plane(d->H, d->W, 32) <= 2 * 512;
     const int tw = cw128 ? 32 : WINO_TILES;
     k.tiles_per_img = (ntiles + tw - 1) / tw;
     k.plane = wino_plane(d->H, d->W, tw);
@@ -896,7 +898,7 @@ extern "C" int scm_conv3x3_wino(const scm_conv3x3_desc* d, void* stream) {
     const bool circ = d->pad_mode == SCM_PAD_CIRCULAR;
 #define SCM_WINO_P(NJ_, G_, CW_) (circ ? launch_wino<NJ_, G_, 1, CW_>(k, groups, s) : launch_wino<NJ_, G_, 0, CW_>(k, groups, s))
 #define SCM_WINO_G(NJ_, CW_) (g == 2 ? SCM_WINO_P(NJ_, 2, CW_) : (g == 1 ? SCM_WINO_P(NJ_, 1, CW_) : SCM_WINO_P(NJ_, 0, CW_)))
-    if (cw128) return SCM_WINO_G(1, 128);          // (W <= 64: the raw rows of 32 patches fit one pair per thread)
+    if (cw128) return k.plane <= 512 ? SCM_WINO_G(1, 128) : SCM_WINO_G(2, 128);
     if (k.plane <= 512) return SCM_WINO_G(1, 64);
     return SCM_WINO_G(2, 64);
 #undef SCM_WINO_G
