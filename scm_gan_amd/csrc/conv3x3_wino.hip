@@ -887,8 +887,11 @@ extern "C" int scm_conv3x3_wino(const scm_conv3x3_desc* d, void* stream) {
     // (one raw pixel pair per thread up to 512 floats per channel, two up to 1 024: W = 2 with H > 126 fits neither)
     // (32 consecutive patches are whole patch rows -- W = 16, 32, 64 -- or an aligned part of one: W = 128, 192, ...;
     // their raw rows take one or two pixel pairs per thread)
-    const bool cw128 = !no128 && (d->cout & 127) == 0 && (d->co1 & 31) == 0 && ntiles % 32 == 0 &&
-                       ((tcw <= 32 && 32 % tcw == 0) || tcw % 32 == 0) && wino_plane(d->H, d->W, 32) <= 2 * 512;
+    static const int any128 = getenv("SCM_WINO_128_ANY") ? atoi(getenv("SCM_WINO_128_ANY")) : 1;
+    const bool aligned32 = ntiles % 32 == 0 && ((tcw <= 32 && 32 % tcw == 0) || tcw % 32 == 0);
+    // (any128: also runs of 32 patches that straddle patch rows and a ragged last workgroup -- 84 x 84, BASELINE configs[3])
+    const bool cw128 = !no128 && (d->cout & 127) == 0 && (d->co1 & 31) == 0 && (aligned32 || any128) &&
+                       wino_plane(d->H, d->W, 32) <= 2 * 512;
     const int tw = cw128 ? 32 : WINO_TILES;
     k.tiles_per_img = (ntiles + tw - 1) / tw;
     k.plane = wino_plane(d->H, d->W, tw);

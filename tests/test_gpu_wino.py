@@ -21,7 +21,11 @@ SHAPES = [  # B, c1, c2, cout, H, W, circular, act
     (1, 16, 0, 64, 20, 12, 0, 1), (3, 64, 0, 48, 20, 12, 0, 0), (1, 128, 0, 128, 64, 64, 1, 1),
     (1, 21, 0, 128, 84, 84, 1, 1), (1, 8, 0, 256, 16, 16, 1, 0), (1, 128, 0, 128, 128, 128, 0, 1),
     (2, 40, 0, 70, 9, 8, 1, 1), (2, 40, 0, 70, 9, 8, 0, 2), (1, 24, 0, 64, 33, 22, 1, 0), (2, 16, 8, 100, 6, 6, 0, 1),
-    (1, 12, 0, 64, 2, 2, 1, 0), (1, 12, 0, 64, 3, 6, 0, 0), (2, 128, 0, 128, 32, 32, 1, 1), (1, 64, 0, 64, 10, 100, 0, 1)]
+    (1, 12, 0, 64, 2, 2, 1, 0), (1, 12, 0, 64, 3, 6, 0, 0), (2, 128, 0, 128, 32, 32, 1, 1), (1, 64, 0, 64, 10, 100, 0, 1),
+    # 128-channel workgroups on runs of 32 patches that straddle patch rows, with a ragged last workgroup: 84 x 84
+    # (BASELINE configs[3]), odd heights, a 6-patch row; 128-wide frames with two input tensors
+    (2, 128, 0, 128, 84, 84, 1, 1), (1, 128, 128, 128, 84, 84, 0, 1), (2, 32, 0, 128, 33, 22, 1, 1), (3, 64, 0, 128, 20, 12, 0, 0),
+    (1, 128, 128, 256, 128, 128, 1, 1)]
 WSHAPES = [
     (2, 64, 0, 64, 16, 16, 1, 1), (2, 128, 128, 128, 16, 16, 1, 1), (2, 128, 0, 128, 16, 16, 0, 1),
     (1, 64, 0, 64, 20, 12, 0, 1), (3, 64, 0, 48, 20, 12, 0, 0), (1, 128, 0, 128, 64, 64, 1, 1),
