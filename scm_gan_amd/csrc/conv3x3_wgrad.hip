@@ -583,6 +583,8 @@ static int wgrad_plan(int B, int H, int W, int cin, int cout, WgradPlan* p) {
     p->rows_per_split = (H + spi - 1) / spi;
     p->spi = (H + p->rows_per_split - 1) / p->rows_per_split;
     p->nsplit = B * p->spi;
+    p->ws_splits = p->nsplit;
+    if (p->m16 && B * ((W + 31) / 32) > p->ws_splits) p->ws_splits = B * ((W + 31) / 32);
     return SCM_OK;
 }
 
@@ -591,8 +593,8 @@ extern "C" int scm_conv3x3_wgrad_workspace(int B, int H, int W, int cin, int cou
     SCM_REQUIRE(B > 0 && H > 0 && W > 0 && cin > 0 && cout > 0, "scm_conv3x3_wgrad_workspace: bad shape");
     WgradPlan p;
     wgrad_plan(B, H, W, cin, cout, &p);
-    if (part_floats) *part_floats = (size_t)p.nsplit * 9 * cout * cin;
-    if (csum_floats) *csum_floats = (size_t)p.nsplit * cout;
+    if (part_floats) *part_floats = (size_t)p.ws_splits * 9 * cout * cin;
+    if (csum_floats) *csum_floats = (size_t)p.ws_splits * cout;
     return SCM_OK;
 }
 
@@ -669,9 +671,9 @@ static int wgrad_impl(const scm_conv3x3_wgrad_desc* d, int precision, void* stre
     if (precision == SCM_ALGO_WINO && d->cout >= 48 && cin >= 48 && scm_wgrad_wino_serves(a)) {
         // Winograd F(2x2,3x3) on the f32 MFMA pipe (conv3x3_wgrad_wino.hip); same slabs, its own (coarser) split
         rc = scm_launch_wgrad_wino(a, p.nsplit, &p.nsplit, &p.spi, s);
-    } else if (precision == SCM_ALGO_WINO && p.m16 && scm_wgrad_wino16_serves(a, p.nsplit)) {
+    } else if (precision == SCM_ALGO_WINO && p.m16 && scm_wgrad_wino16_serves(a, p.ws_splits)) {
         // the same algorithm for the 16-channel-side layers (conv3x3_wgrad_wino16.hip)
-        rc = scm_launch_wgrad_wino16(a, p.nsplit, &p.nsplit, &p.spi, s);
+        rc = scm_launch_wgrad_wino16(a, p.ws_splits, &p.nsplit, &p.spi, s);
     } else if (precision == SCM_ALGO_WINO) {
         return wgrad_impl(d, SCM_PREC_F32, stream);          // shapes it does not take: the direct kernels
     } else if (precision == SCM_PREC_BF16X3 && d->cout > 64 && p.m16 == 0 && p.mt == 4) {

@@ -472,7 +472,7 @@ int scm_launch_wgrad_wino(const WgradKArgs& k, int max_splits, int* nsplit_out, 
     const bool circ = a.pad_mode == SCM_PAD_CIRCULAR;
     const int g = a.gate_act == 0 ? 0 : ((a.gate_mask && a.gate_act == SCM_ACT_LRELU) ? 2 : 1);
     dim3 grid(a.B * a.spi, cog * cig);
-    if (!edge && scm_wgrad_winoz_serves(a)) {
+    if (scm_wgrad_winoz_serves(a)) {        // (ragged last strips included; odd heights / ragged channel groups are not)
         const int rc = scm_launch_wgrad_winoz(a, grid, s);      // (declines bands that are not whole groups of four chunks)
         if (rc != SCM_EUNSUPPORTED) return rc;
     }

@@ -80,7 +80,9 @@ __device__ __forceinline__ f32x2 wz_mul(f32x2 a, f32x2 b) {
 }
 
 // GATED: 0 none, 1 gate tensor (act' from the saved output), 2 1-bit leaky-relu mask.  PADC: circular padding.
-template <int GATED, int PADC>
+// EDGE: the last 8-patch strip of a patch row is ragged (W % 32 != 0, W % 4 == 0: 84 x 84, BASELINE configs[3]): a patch
+// pair past the row end stages zeros as its output gradient (and reads the row's last real pair: finite data).
+template <int GATED, int PADC, int EDGE>
 __global__ void __launch_bounds__(256, 1) conv3x3_wgrad_winoz_kernel(const WgradKArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const DYL = smem;                     // 2 stages of the DY image
@@ -93,8 +95,8 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wgrad_winoz_kernel(const Wgrad
     const int wm = wave >> 1, wn = wave & 1;
     const int q = tid & 3, ch = tid >> 2;        // this thread's patch pair of a chunk and channel of the group
     const int W = a.W, H = a.H, HW = H * W;
-    const int TCW = W >> 1, TRH = H >> 1;        // (H even, TCW % 16 == 0: host check)
-    const int nchr = TCW >> 3;                   // 8-patch strips per patch row (even)
+    const int TCW = W >> 1, TRH = H >> 1;        // (H even, W % 4 == 0: host check)
+    const int nchr = (TCW + 7) >> 3;             // 8-patch strips per patch row (even: host check)
 
     int split, grp;
     scm_xcd_split_group(a.spi, split, grp);
@@ -146,6 +148,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wgrad_winoz_kernel(const Wgrad
     u32x4z mr[2][GATED == 2 ? 2 : 1];
     unsigned o_xm[2], o_x0[2], o_x5[2], o_dm[2], o_mm[2];     // per-strip lane offsets (they change with the strip pair only)
     f32x2 emask[2];                                            // zero padding: (c0 exists, c5 exists)
+    f32x2 dmask[2];                                            // EDGE: this thread's patch pair of the strip exists (1, 1) or not (0, 0)
     int c_ty[2] = {0, 0};                                      // patch row of the chunk held in each strip's registers
     bool c_fresh[2] = {true, true};                            // ... all four rows were loaded (top of a column)
     bool c_sum[2] = {false, false};                            // ... its output gradient enters the channel sums
@@ -157,7 +160,12 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wgrad_winoz_kernel(const Wgrad
     int kl = 0, pl = 0, kkl = 0;
     auto strip_offsets = [&](auto s_, int cx) {
         constexpr int S = decltype(s_)::value;
-        const int ix0 = 16 * cx + 4 * q;                 // first image column of the pair's outputs
+        int ix0 = 16 * cx + 4 * q;                       // first image column of the pair's outputs
+        if constexpr (EDGE) {
+            const bool real = ix0 < W;                   // (W % 4 == 0: a pair exists as a whole or not at all)
+            dmask[S][0] = real ? 1.f : 0.f; dmask[S][1] = dmask[S][0];
+            ix0 = real ? ix0 : W - 4;
+        }
         int i0 = ix0 - 1, i5 = ix0 + 4;
         const bool in0 = i0 >= 0, in5 = i5 < W;
         i0 = in0 ? i0 : (PADC ? W - 1 : 0);
@@ -240,6 +248,14 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wgrad_winoz_kernel(const Wgrad
                 if (c_ty[S] == 0) { xm[S][R][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; xe[S][R][0] = (f32x2){0.f, 0.f}; }     // image row -1
             }
             if (c_ty[S] == TRH - 1) { xm[S][R ^ 1][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; xe[S][R ^ 1][1] = (f32x2){0.f, 0.f}; }   // row H
+        }
+        if constexpr (EDGE) {
+            const f32x2 dm = dmask[S];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const f32x2 lo = wz_mul((f32x2){dr[S][i][0], dr[S][i][1]}, dm), hi = wz_mul((f32x2){dr[S][i][2], dr[S][i][3]}, dm);
+                dr[S][i] = (f32x4){lo[0], lo[1], hi[0], hi[1]};
+            }
         }
         if constexpr (GATED == 1) {
 #pragma unroll
@@ -489,10 +505,10 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wgrad_winoz_kernel(const Wgrad
 }
 
 // ------------------------------------------------------------------ host
-template <int GATED, int PADC>
-static int launch_wz(const WgradKArgs& a, dim3 grid, hipStream_t s) {
+template <int GATED, int PADC, int EDGE>
+static int launch_wz_e(const WgradKArgs& a, dim3 grid, hipStream_t s) {
     const size_t lds = (size_t)4 * WZ_SLAB * sizeof(float);
-    auto kern = conv3x3_wgrad_winoz_kernel<GATED, PADC>;
+    auto kern = conv3x3_wgrad_winoz_kernel<GATED, PADC, EDGE>;
     static std::atomic<uint64_t> attr_done{0};       // per (instantiation, device)
     if (int rc = scm_ensure_lds_attr(reinterpret_cast<const void*>(kern), attr_done, 160 * 1024)) return rc;
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
@@ -500,17 +516,23 @@ static int launch_wz(const WgradKArgs& a, dim3 grid, hipStream_t s) {
     return SCM_OK;
 }
 
-// What this form takes of what scm_wgrad_wino_serves() accepts: even heights, whole PAIRS of 8-patch strips per patch
-// row, whole 64-channel output groups.
+template <int GATED, int PADC>
+static int launch_wz(const WgradKArgs& a, dim3 grid, hipStream_t s) {
+    return (a.W & 31) ? launch_wz_e<GATED, PADC, 1>(a, grid, s) : launch_wz_e<GATED, PADC, 0>(a, grid, s);
+}
+
+// What this form takes of what scm_wgrad_wino_serves() accepts: even heights, an even number of 8-patch strips per patch
+// row (the last one may be ragged: W % 4 == 0), whole 64-channel output groups.
 bool scm_wgrad_winoz_serves(const WgradKArgs& a) {
     static const int off = getenv("SCM_NO_WGRAD_WINOZ") ? atoi(getenv("SCM_NO_WGRAD_WINOZ")) : 0;
-    return !off && (a.H & 1) == 0 && (a.W & 31) == 0 && (a.cout & 63) == 0;
+    const int nchr = (a.W / 2 + 7) / 8;
+    return !off && (a.H & 1) == 0 && (a.W & 3) == 0 && a.W >= 32 && (nchr & 1) == 0 && (a.cout & 63) == 0;
 }
 
 // `a` arrives with the split of scm_launch_wgrad_wino (spi, rows_per_split, ci_groups) filled in.  Returns
 // SCM_EUNSUPPORTED (nothing launched, no error text) when a band would not be whole groups of four chunks.
 int scm_launch_wgrad_winoz(const WgradKArgs& a, dim3 grid, hipStream_t s) {
-    const int trh = a.H / 2, nchr = a.W / 32 * 2;
+    const int trh = a.H / 2, nchr = (a.W / 2 + 7) / 8;
     const int last = trh - (a.spi - 1) * a.rows_per_split;          // patch rows of an image's last band
     if ((a.rows_per_split * nchr) % 4 != 0 || (last * nchr) % 4 != 0 || last < 1) return SCM_EUNSUPPORTED;
     const bool circ = a.pad_mode == SCM_PAD_CIRCULAR;

@@ -35,6 +35,8 @@ __device__ __forceinline__ void scm_xcd_split_group(int spi, int& split, int& gr
 
 struct WgradPlan {
     int mt, nt, spi, rows_per_split, nseg, PS, co_groups, ci_groups, nsplit, m16;
+    int ws_splits;      // partial slabs the workspaces are sized for (>= nsplit: the thin Winograd form splits a row into
+                        // 32-column parts and needs B * ceil(W / 32) of them)
 };
 
 // 128 co x 64 ci tiles on v_mfma_f32_32x32x16_{f16,bf16} (conv3x3_wgrad_h16.hip)

@@ -35,7 +35,9 @@ WSHAPES = [
     # bands of several patch rows on frames with W % 32 == 0: the zigzag form (conv3x3_wgrad_winoz.hip) -- carried rows,
     # role swaps, strip pairs, zero padding at the top / bottom band, two input tensors, ungated / float / 1-bit gates
     (8, 128, 0, 128, 64, 64, 1, 1), (8, 64, 64, 128, 64, 64, 0, 1), (64, 64, 0, 64, 32, 32, 1, 0),
-    (3, 128, 0, 128, 128, 128, 0, 1), (2, 64, 0, 64, 64, 32, 0, 0)]
+    (3, 128, 0, 128, 128, 128, 0, 1), (2, 64, 0, 64, 64, 32, 0, 0),
+    # ... with a ragged last strip (W % 32 != 0, W % 4 == 0): 84 x 84 (BASELINE configs[3]) in bands of 6 and 2 patch rows, 20 x 52
+    (8, 128, 0, 128, 84, 84, 1, 1), (4, 64, 64, 64, 84, 84, 0, 1), (4, 64, 0, 64, 20, 52, 1, 0)]
 
 
 @pytest.fixture(scope="module")
