@@ -421,6 +421,9 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wgrad_winoz_kernel(const Wgrad
         group(s_, r_, r1_, IC(4)); group(s_, r_, r1_, IC(5)); group(s_, r_, r1_, IC(6)); group(s_, r_, r1_, IC(7));
         group(s_, r_, r1_, IC(8)); group(s_, r_, r1_, IC(9)); group(s_, r_, r1_, IC(10)); group(s_, r_, r1_, IC(11));
         group(s_, r_, r1_, IC(12)); group(s_, r_, r1_, IC(13)); group(s_, r_, r1_, IC(14)); group(s_, r_, r1_, IC(15));
+        // (the image stores are inline asm: the compiler does not count them -- the explicit wait makes the barrier's
+        // guarantee independent of where the last operand-read wait happens to sit)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __syncthreads();            // the other stage holds chunk k+1; every wave is done with this one
         SB();
     };
@@ -440,6 +443,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wgrad_winoz_kernel(const Wgrad
     dy_calc(IC(0), IC(2)); dy_store(IC(0), IC(2)); dy_calc(IC(0), IC(3)); dy_store(IC(0), IC(3));
     x_calc(IC(0), IC(0), IC(0)); x_store(IC(0), IC(0)); x_calc(IC(0), IC(0), IC(1)); x_store(IC(0), IC(1));
     x_calc(IC(0), IC(0), IC(2)); x_store(IC(0), IC(2)); x_calc(IC(0), IC(0), IC(3)); x_store(IC(0), IC(3));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
     WZ_TICK(0);
     // Chunk k: strip k & 1, role (k >> 1) & 1; the chunk it transforms, k + 1, has role ((k + 1) >> 1) & 1.  The
