@@ -190,7 +190,8 @@ __global__ void __launch_bounds__(SN_THREADS) sn_fold_kernel(const float* __rest
     const float dot = block_sum_1024(part, red);
     const float is = *inv_sigma;
     const float c = dot * is * is;
-    for (int i = threadIdx.x; i < n; i += SN_THREADS) {
+    // (every workgroup of the launch computed the same dot, in the same order; each applies the fold to its slice)
+    for (int i = blockIdx.x * SN_THREADS + threadIdx.x; i < n; i += gridDim.x * SN_THREADS) {
         const int r = i / cols, j = i - r * cols;
         const float val = g[i] * is - c * u[r] * v[j];
         dwbar[i] = accumulate ? dwbar[i] + val : val;
@@ -234,7 +235,11 @@ extern "C" int scm_sn_fold_grad(const float* g, const float* w_bar, const float*
         SCM_LAUNCH_CHECK("sn_fold_parts_kernel");
         return SCM_OK;
     }
-    hipLaunchKernelGGL(sn_fold_kernel, dim3(1), dim3(SN_THREADS), 0, (hipStream_t)stream, g, w_bar, u, v, inv_sigma,
+    // (up to 16 workgroups: each re-reads g and W_bar for the dot -- they sit in L2 -- and writes 1/16 of the matrix)
+    int nb = (rows * cols + 4 * SN_THREADS - 1) / (4 * SN_THREADS);
+    nb = nb < 1 ? 1 : (nb > 16 ? 16 : nb);
+    if (dw_bar == g || dw_bar == w_bar) nb = 1;       // (in place: one workgroup, which finishes the dot before it writes)
+    hipLaunchKernelGGL(sn_fold_kernel, dim3(nb), dim3(SN_THREADS), 0, (hipStream_t)stream, g, w_bar, u, v, inv_sigma,
                        rows, cols, accumulate, dw_bar);
     SCM_LAUNCH_CHECK("sn_fold_kernel");
     return SCM_OK;
