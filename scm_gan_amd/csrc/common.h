@@ -67,6 +67,39 @@ __device__ __forceinline__ float scm_act_grad_from_out(float y, int act) {
     return 1.f;
 }
 
+// Packed fp32 forms with their operand selects spelled out (left to the compiler they are scalarised or built from
+// moves; next to f32 MFMAs every VALU instruction is paid for)
+__device__ __forceinline__ f32x2 scm_pk_add(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f32x2 scm_pk_sub(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f32x2 scm_pk_sumdiff(f32x2 p) {            // (p.x + p.y, p.x - p.y)
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(p));
+    return d;
+}
+__device__ __forceinline__ f32x2 scm_pk_addsub(f32x2 t, f32x2 p) {     // (t.x + p.x, t.y - p.y)
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(d) : "v"(t), "v"(p));
+    return d;
+}
+__device__ __forceinline__ f32x2 scm_pk_fma(f32x2 a, f32x2 b, f32x2 c) {
+    f32x2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ f32x2 scm_pk_mul(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

@@ -59,6 +59,8 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_k16_kernel(const ConvKArg
 
     int b, wt, cg_;
     scm_xcd_tile_map(a.B, a.tiles_per_img, b, wt, cg_);
+    b = __builtin_amdgcn_readfirstlane(b);          // (block-uniform by construction; said so for the scalar row bases below)
+    wt = __builtin_amdgcn_readfirstlane(wt);
     const int t0 = wt * K16_TILES;
     const int ty0 = t0 / TCW;
     int tlast = t0 + K16_TILES - 1;
@@ -189,6 +191,12 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_k16_kernel(const ConvKArg
         }
 
     // ---- the output-channel tiles
+    // (fast epilogue: every patch of the workgroup exists with both of its rows; 32-bit lane offsets of this lane's
+    // output patches inside a block of 4 channel planes)
+    const bool all_valid = t0 + K16_TILES <= ntiles && (H & 1) == 0 ;
+    unsigned yoff[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) yoff[k] = (unsigned)(4 * lq) * (unsigned)plane_b + (unsigned)p00[k] * 4u;
     const float sc = a.scale ? *a.scale : 1.f;
     const float slope = scm_act_slope(a.act);
     const int co2n = a.cout - a.co1;
@@ -329,8 +337,114 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_k16_kernel(const ConvKArg
                 }
             }
         };
-        if (a.mask_out) { if (gm) epi(std::true_type{}, std::true_type{}); else epi(std::true_type{}, std::false_type{}); }
-        else { if (gm) epi(std::false_type{}, std::true_type{}); else epi(std::false_type{}, std::false_type{}); }
+        // Fast path (block-uniform; every launch of the training step takes it): all 64 patches of the workgroup exist
+        // with both rows, the tile's 16 channels exist, nothing is accumulated.  As in conv3x3_wino.hip's: scalar row
+        // bases + one 32-bit lane offset (no per-store 64-bit address arithmetic), no per-value predicates or divergent
+        // branches, the output transform on register pairs -- the general path above held ~1 200 instructions per tile of
+        // 64 MFMAs (tools/isa_loop_stats.py), 47 of them divergent branches.
+        auto epi_fast = [&](auto mo_, auto yg_) {
+            constexpr bool MO = decltype(mo_)::value, YG = decltype(yg_)::value;
+            typedef __attribute__((address_space(1))) char* gwp;
+            typedef __attribute__((address_space(1))) f32x2* gw2;
+            typedef const __attribute__((address_space(1))) u32x2k* ggp;
+            // (the tile's base address is block-uniform; the compiler keeps the general path's copy of it in VGPRs, so it
+            // is handed to the scalar unit explicitly: two v_readfirstlane per tile)
+            const unsigned long long ybv = (unsigned long long)(first ? a.y1 + ((size_t)b * a.co1 + cobase) * HW
+                                                                      : a.y2 + ((size_t)b * co2n + (cobase - a.co1)) * HW);
+            // (readfirstlane returns a signed int: through `unsigned`, or an address with bit 31 set would sign-extend)
+            const unsigned yb_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ybv >> 32));
+            const unsigned yb_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ybv);
+            gwp yb = (gwp)(((unsigned long long)yb_hi << 32) | (unsigned long long)yb_lo);
+            const unsigned wrow = (unsigned)W * 4u;
+            f32x2 sc2, sl2;
+            sc2[0] = sc; sc2[1] = sc; sl2[0] = slope; sl2[1] = slope;
+            unsigned bits[NB][4];
+#pragma unroll
+            for (int k = 0; k < NB; ++k) bits[k][0] = bits[k][1] = bits[k][2] = bits[k][3] = 0u;
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                unsigned gw[4] = {~0u, ~0u, ~0u, ~0u};
+                if constexpr (YG) {
+                    const int gnw = ((first ? a.co1 : co2n) + 31) >> 5;
+                    ggp gp = (ggp)(gm + ((size_t)b * gnw + (cd0 >> 5)) * HW);
+                    const u32x2k g0 = *(ggp)((const __attribute__((address_space(1))) char*)gp + (unsigned)p00[k] * 4u);
+                    const u32x2k g1 = *(ggp)((const __attribute__((address_space(1))) char*)gp + (unsigned)p00[k] * 4u + wrow);
+                    gw[0] = g0[0]; gw[1] = g0[1]; gw[2] = g1[0]; gw[3] = g1[1];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int col = 4 * lq + r, co = cobase + col;
+                    f32x2 m03[4], m12[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        m03[i][0] = acc[4 * i][k][r]; m03[i][1] = acc[4 * i + 3][k][r];
+                        m12[i][0] = acc[4 * i + 1][k][r]; m12[i][1] = acc[4 * i + 2][k][r];
+                    }
+                    const f32x2 s0_03 = scm_pk_add(scm_pk_add(m03[0], m03[1]), m03[2]);
+                    const f32x2 s0_12 = scm_pk_add(scm_pk_add(m12[0], m12[1]), m12[2]);
+                    const f32x2 s1_03 = scm_pk_sub(scm_pk_sub(m03[1], m03[2]), m03[3]);
+                    const f32x2 s1_12 = scm_pk_sub(scm_pk_sub(m12[1], m12[2]), m12[3]);
+                    f32x2 oa = scm_pk_addsub(scm_pk_sumdiff(s0_12), s0_03);       // image row oy:     (o0, o1)
+                    f32x2 ob = scm_pk_addsub(scm_pk_sumdiff(s1_12), s1_03);       // image row oy + 1: (o2, o3)
+                    f32x2 bb;
+                    bb[0] = BIASL[co]; bb[1] = bb[0];
+                    oa = scm_pk_fma(oa, sc2, bb);
+                    ob = scm_pk_fma(ob, sc2, bb);
+                    const f32x2 la = scm_pk_mul(oa, sl2), lb = scm_pk_mul(ob, sl2);
+                    float o[4];
+                    o[0] = fmaxf(oa[0], la[0]); o[1] = fmaxf(oa[1], la[1]);      // none (slope 1) / leaky_relu (0.01)
+                    o[2] = fmaxf(ob[0], lb[0]); o[3] = fmaxf(ob[1], lb[1]);
+                    const unsigned gbit = 1u << ((cd0 + col) & 31);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if constexpr (MO) bits[k][q] |= (o[q] > 0.f ? 1u : 0u) << (co & 31);
+                        if constexpr (YG) o[q] = (gw[q] & gbit) ? o[q] : 0.01f * o[q];
+                    }
+                    gwp rb = yb + (size_t)r * plane_b;
+                    asm volatile("" : "+s"(rb));
+                    const f32x2 v0 = {o[0], o[1]}, v1 = {o[2], o[3]};
+                    *(gw2)(rb + yoff[k]) = v0;
+                    *(gw2)(rb + wrow + yoff[k]) = v1;
+                }
+            }
+            if constexpr (MO) {       // the 1-bit leaky-relu gate: a tile is 16 channels of a 32-channel word
+#pragma unroll
+                for (int k = 0; k < NB; ++k)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        unsigned v = bits[k][q];
+                        v |= __shfl_xor(v, 16);
+                        v |= __shfl_xor(v, 32);
+                        bits[k][q] = v;
+                    }
+                const bool odd = ct & 1, last = ct == ncot - 1;
+                if (odd || last) {
+                    if (lq == 0) {
+#pragma unroll
+                        for (int k = 0; k < NB; ++k) {
+                            unsigned* dst = a.mask_out + ((size_t)b * nwo + (ct >> 1)) * HW + p00[k];
+                            const unsigned w0 = bits[k][0] | (odd ? keep[k][0] : 0u), w1 = bits[k][1] | (odd ? keep[k][1] : 0u);
+                            const unsigned w2 = bits[k][2] | (odd ? keep[k][2] : 0u), w3 = bits[k][3] | (odd ? keep[k][3] : 0u);
+                            *reinterpret_cast<u32x2k*>(dst) = u32x2k{w0, w1};
+                            *reinterpret_cast<u32x2k*>(dst + W) = u32x2k{w2, w3};
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < NB; ++k)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) keep[k][q] = bits[k][q];
+                }
+            }
+        };
+        const bool fast = all_valid && !addp && cobase + 16 <= a.cout;
+        if (fast) {
+            if (a.mask_out) { if (gm) epi_fast(std::true_type{}, std::true_type{}); else epi_fast(std::true_type{}, std::false_type{}); }
+            else { if (gm) epi_fast(std::false_type{}, std::true_type{}); else epi_fast(std::false_type{}, std::false_type{}); }
+        } else {
+            if (a.mask_out) { if (gm) epi(std::true_type{}, std::true_type{}); else epi(std::true_type{}, std::false_type{}); }
+            else { if (gm) epi(std::false_type{}, std::true_type{}); else epi(std::false_type{}, std::false_type{}); }
+        }
     }
 #undef SB
 #undef IC
