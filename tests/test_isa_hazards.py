@@ -16,3 +16,14 @@ def test_inline_asm_mfma_kernels_have_no_unpadded_hazards(tmp_path):
     for path in chk.build(str(tmp_path)):
         nmfma, hazards, copies = chk.check(path)
         assert nmfma >= 256 and hazards == 0 and copies == 0, (path, nmfma, hazards, copies)
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not on PATH")
+def test_inline_asm_lds_stores_are_waited_for_before_barriers(tmp_path):
+    """conv3x3_wgrad_winoz.hip: its image stores are inline asm, which the compiler's s_waitcnt bookkeeping does not see --
+    every barrier must have an explicit lgkmcnt(0) wait behind the last store in front of it (round 4 found the prologue's
+    barrier without one)."""
+    import isa_hazard_check as chk
+    for path in chk.build_lds(str(tmp_path)):
+        seen, bad = chk.check_lds_stores_before_barriers(path)
+        assert seen >= 12 and bad == 0, (path, seen, bad)

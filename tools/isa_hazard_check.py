@@ -93,3 +93,48 @@ def main(argv):
 
 if __name__ == "__main__":
     sys.exit(main(sys.argv[1:]))
+
+
+# ---------------------------------------------------------------- inline-asm LDS stores in front of a barrier
+LDS_ASM_FILES = ("conv3x3_wgrad_winoz.hip",)
+
+
+def check_lds_stores_before_barriers(path):
+    """conv3x3_wgrad_winoz.hip issues its operand-image stores as inline `ds_write_b64`: the compiler does not count them,
+    so it inserts no `s_waitcnt lgkmcnt(0)` for them in front of an `s_barrier`.  Walks every straight-line stretch that
+    ends in a barrier: after the last ds_write there must be an lgkmcnt(0) wait before the barrier.  Returns
+    (barriers seen, barriers with an unwaited store in front)."""
+    raw = open(path).read().split("\n")
+    lines = [l.strip() for l in raw if l.strip() and not l.strip().startswith((";", ".")) or l.strip().startswith(".LBB")]
+    seen = bad = 0
+    for i, l in enumerate(lines):
+        if not l.startswith("s_barrier"):
+            continue
+        seen += 1
+        j = i - 1
+        waited = False
+        while j >= 0:
+            p = lines[j]
+            if p.startswith(".LBB") or p.startswith("s_barrier") or p.startswith("s_endpgm") or p.startswith("s_cbranch") \
+                    or p.startswith("s_branch"):
+                break
+            if p.startswith("s_waitcnt") and ("lgkmcnt(0)" in p or p.split()[-1] == "0"):
+                waited = True
+            if p.startswith("ds_write") and not waited:
+                bad += 1
+                break
+            if p.startswith("ds_write"):
+                break
+            j -= 1
+    return seen, bad
+
+
+def build_lds(outdir):
+    outs = []
+    for f in LDS_ASM_FILES:
+        out = os.path.join(outdir, f + ".s")
+        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-x", "hip", "--cuda-device-only", "-S",
+                               "-w", "-I", os.path.join(ROOT, "scm_gan_amd", "csrc"), "-I", os.path.join(ROOT, "include"),
+                               os.path.join(ROOT, "scm_gan_amd", "csrc", f), "-o", out])
+        outs.append(out)
+    return outs
