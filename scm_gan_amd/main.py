@@ -149,6 +149,22 @@ def decoder_frame_loss(decoder, z, target, kind=0):
     return decoder_pixel_loss(target, logits) if kind == 0 else ops.pixel_mse(logits, target)
 
 
+def _heads_time_batched(a, decoder, reward_predictor, z, nsteps):
+    """Whether Trainer.step runs the reward head and the decoder once over all unrolled steps (time-batched) instead
+    of once per step: when both take their fused kernels on this latent (what the measurement behind it covers), more
+    than one step is unrolled and no option reads the running mask inside the loop (--latent-overshooting does).
+    SCM_BATCHED_HEADS=0 keeps the per-step launches (A/B), =1 batches whatever the modules are (CPU host-logic tests)."""
+    mode = os.environ.get("SCM_BATCHED_HEADS", "")
+    if mode == "0" or nsteps < 2 or a.latent_overshooting:
+        return False
+    if mode == "1":
+        return True
+    try:
+        return bool(decoder._fused() and reward_predictor._fused(z))
+    except AttributeError:
+        return False
+
+
 class Trainer(object):
     """One training iteration of main.py:143-297 on device-resident batches.
 
@@ -238,17 +254,28 @@ class Trainer(object):
         loss = 0
         lo_loss = 0
         lo_z_set = {}
+        # Time-batched heads: the reward head and the decoder + pixel loss of main.py:181-190 consume z_t and feed
+        # nothing back into the rollout, so the steps' latents are collected and both run ONCE over (horizon-2) x B
+        # samples behind the loop -- same per-sample arithmetic, same per-step losses in the same order; what changes
+        # is that one launch covers whole images per workgroup instead of 8-row bands with their halo rows
+        # (tools/bench_heads.py: 8 x 64 samples 4.8 ms, 1 x 512 samples 3.5 ms forward + backward).
+        heads_batched = _heads_time_batched(a, decoder, reward_predictor, z, prediction_horizon - 2)
+        zs = []
         for t in range(1, prediction_horizon - 1):                             # main.py:177
-            expected_reward = reward_predictor(z)                              # main.py:181
-            rec_loss_batch = decoder_frame_loss(decoder, z, targets[t])        # main.py:188-190
+            if heads_batched:
+                zs.append(z)
+            else:
+                expected_reward = reward_predictor(z)                              # main.py:181
+                rec_loss_batch = decoder_frame_loss(decoder, z, targets[t])        # main.py:188-190
             if a.truncate_bptt and t > 1:
                 z = z.detach()
-            # main.py:178,182-185,195-197 in one launch: mask update, both masked means, loss accumulation
-            loss, reward_difference, rec_loss, active_mask = ops.StepLossFn.apply(
-                loss if torch.is_tensor(loss) else None, expected_reward, rec_loss_batch, rewards[:, t], dones[:, t],
-                active_mask, theta * a.reward_coef)
-            ts.collect('Rd Loss t={}'.format(t), reward_difference)
-            ts.collect('Reconstruction t={}'.format(t), rec_loss)
+            if not heads_batched:
+                # main.py:178,182-185,195-197 in one launch: mask update, both masked means, loss accumulation
+                loss, reward_difference, rec_loss, active_mask = ops.StepLossFn.apply(
+                    loss if torch.is_tensor(loss) else None, expected_reward, rec_loss_batch, rewards[:, t], dones[:, t],
+                    active_mask, theta * a.reward_coef)
+                ts.collect('Rd Loss t={}'.format(t), reward_difference)
+                ts.collect('Reconstruction t={}'.format(t), rec_loss)
 
             if t == 2:
                 main_stream.wait_stream(self.side_stream)                      # (the remaining calls' power iterations)
@@ -262,6 +289,19 @@ class Trainer(object):
                 for t_a in range(2, t - 1):
                     lo_loss_batch = latent_state_loss(lo_z_set[t].detach(), lo_z_set[t_a])
                     lo_loss += a.td_lambda * torch.mean(lo_loss_batch * active_mask)
+
+        if heads_batched:
+            nT = len(zs)
+            z_all = torch.cat(zs, 0)                                           # (nT * B, L, H, W), step-major
+            frames_all = targets[1:1 + nT].reshape((nT * batch_size,) + tuple(targets.shape[2:]))
+            expected_reward = reward_predictor(z_all)                          # main.py:181, all steps
+            rec_loss_batch = decoder_frame_loss(decoder, z_all, frames_all)    # main.py:188-190, all steps
+            loss, rd_rec, active_mask = ops.StepLossSeqFn.apply(expected_reward, rec_loss_batch, rewards, dones, 1, nT,
+                                                                active_mask, theta * a.reward_coef)
+            for i in range(nT):
+                ts.collect('Rd Loss t={}'.format(1 + i), rd_rec[i, 0:1])
+                ts.collect('Reconstruction t={}'.format(1 + i), rd_rec[i, 1:2])
+            del zs, z_all
 
         if a.latent_overshooting:
             ts.collect('LO total', lo_loss)

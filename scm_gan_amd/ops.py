@@ -1052,6 +1052,60 @@ class CSRNSweepsFn(Function):
         return tuple(out)
 
 
+class StepLossSeqFn(Function):
+    """StepLossFn for ALL unrolled steps of an iteration (main.py:177-197 with the decoder / reward head applied to the
+    steps' latents in one time-batched launch each, Trainer.step): rhat_all (nT*B, R) and bce_all (nT*B,) hold step
+    t0 + i in rows [i*B, (i+1)*B); rewards (B, T, R) / dones (B, T) are the iteration's tensors.  The same per-step kernel
+    runs nT times in the reference's order (mask update, both masked means, loss accumulation), reading / writing slices
+    in place: no autograd slicing, bitwise the per-step result.  Returns (loss, rd_rec (nT, 2), final mask)."""
+
+    @staticmethod
+    def forward(ctx, rhat_all, bce_all, rewards, dones, t0, nT, mask0, coef):
+        lib = L.lib()
+        rhat_all, bce_all, mask0 = _chk(rhat_all, "step_loss_seq"), _chk(bce_all, "step_loss_seq"), _chk(mask0, "step_loss_seq")
+        B, R = rhat_all.shape[0] // nT, rhat_all.shape[1]
+        for name, t in (("rewards", rewards), ("dones", dones)):
+            if not t.is_cuda or t.dtype != torch.float32:
+                raise RuntimeError("scm_gan_amd.step_loss_seq: %s must be an fp32 GPU tensor (got %s on %s)"
+                                   % (name, t.dtype, t.device))
+        assert rewards.stride(2) == 1 and rewards.shape[0] == B and dones.shape[0] == B and rhat_all.shape[0] == nT * B
+        losses, rd_rec = _new(rhat_all, nT), _new(rhat_all, nT, 2)
+        masks = _new(rhat_all, nT + 1, B)
+        masks[0].copy_(mask0)
+        for i in range(nT):
+            t = t0 + i
+            L.check(lib.scm_step_loss(ctypes.c_void_p(rhat_all.data_ptr() + 4 * i * B * R),
+                                      ctypes.c_void_p(rewards.data_ptr() + 4 * t * rewards.stride(1)), rewards.stride(0),
+                                      ctypes.c_void_p(dones.data_ptr() + 4 * t * dones.stride(1)), dones.stride(0),
+                                      ctypes.c_void_p(bce_all.data_ptr() + 4 * i * B), _p(masks[i]),
+                                      None if i == 0 else ctypes.c_void_p(losses.data_ptr() + 4 * (i - 1)), B, R, coef,
+                                      _dev("coef"), _p(masks[i + 1]), ctypes.c_void_p(losses.data_ptr() + 4 * i),
+                                      _p(rd_rec[i]), _stream()), "scm_step_loss")
+        ctx.coef = coef
+        ctx.coef_dev = dev_scalars.get("coef")
+        ctx.geom = (t0, nT, B, R)
+        ctx.save_for_backward(rhat_all, rewards, masks)
+        loss, mask_out = losses[nT - 1:nT], masks[nT]
+        ctx.mark_non_differentiable(rd_rec, mask_out)
+        ctx.set_materialize_grads(False)
+        return loss, rd_rec, mask_out
+
+    @staticmethod
+    def backward(ctx, g, g_rd_rec, g_mask):
+        rhat_all, rewards, masks = ctx.saved_tensors
+        t0, nT, B, R = ctx.geom
+        g = _chk(g, "step_loss_seq.backward")
+        d_rhat, d_bce = torch.empty_like(rhat_all), _new(rhat_all, nT * B)
+        for i in range(nT):
+            t = t0 + i
+            L.check(L.lib().scm_step_loss_bwd(ctypes.c_void_p(rhat_all.data_ptr() + 4 * i * B * R),
+                                              ctypes.c_void_p(rewards.data_ptr() + 4 * t * rewards.stride(1)),
+                                              rewards.stride(0), _p(masks[i + 1]), _p(g), B, R, ctx.coef, _p(ctx.coef_dev),
+                                              ctypes.c_void_p(d_rhat.data_ptr() + 4 * i * B * R),
+                                              ctypes.c_void_p(d_bce.data_ptr() + 4 * i * B), _stream()), "scm_step_loss_bwd")
+        return d_rhat, d_bce, None, None, None, None, None, None
+
+
 class StepLossFn(Function):
     """Loss bookkeeping of one unrolled step (main.py:178-197) in one launch; returns
     (loss_out, rd, rec, mask_out).  rewards_t / dones_t may be strided columns."""

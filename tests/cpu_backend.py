@@ -65,6 +65,20 @@ class StepLoss(object):
         return loss, rd.detach(), rec.detach(), mask.detach()
 
 
+class StepLossSeq(object):
+    """ops.StepLossSeqFn.apply: the per-step bookkeeping over the time-batched heads' outputs."""
+
+    @staticmethod
+    def apply(rhat_all, bce_all, rewards, dones, t0, nT, mask0, coef):
+        B = rhat_all.shape[0] // nT
+        loss, mask, rows = None, mask0, []
+        for i in range(nT):
+            loss, rd, rec, mask = StepLoss.apply(loss, rhat_all[i * B:(i + 1) * B], bce_all[i * B:(i + 1) * B],
+                                                 rewards[:, t0 + i], dones[:, t0 + i], mask, coef)
+            rows.append(torch.stack([rd, rec]))
+        return loss, torch.stack(rows), mask
+
+
 def pixel_bce(logit, target):
     return O.decoder_pixel_loss(target, torch.sigmoid(logit))
 
@@ -187,6 +201,7 @@ def install(mp=None):
     setattr_(M, "AdamClip", AdamClipCPU)
     setattr_(M, "decoder_pixel_loss", lambda target, logits: pixel_bce(logits, target))
     setattr_(ops, "StepLossFn", StepLoss)
+    setattr_(ops, "StepLossSeqFn", StepLossSeq)
     setattr_(ops, "pixel_mse", pixel_mse)
     setattr_(ops, "pixel_bce", pixel_bce)
     setattr_(ops, "mean_all", lambda x: x.mean())

@@ -115,11 +115,13 @@ def _flags(case):
             "cf": cf, "cf_no_overlap": cf + ["--no-overlap"]}[case]
 
 
-def _run_step(case, shard, steps=2):
+def _run_step(case, shard, steps=2, batched_heads=False):
     """Trainer.step x `steps` on the samples `shard` of the global batch; returns (reduced flat grads of
-    the last step, weights after it, hook count)."""
+    the last step, weights after it, hook count).  batched_heads: the reward head and the decoder run once over all
+    unrolled steps (main._heads_time_batched) instead of once per step."""
     import cpu_backend as CB
     M = CB.install()
+    os.environ["SCM_BATCHED_HEADS"] = "1" if batched_heads else "0"
     gan = case == "gan"
     states, rewards, dones, actions, noises, dnoise = _batch(gan)
     enc, dec, rp, disc, tr = CB.build_nets(0, A, R, C, L)
@@ -133,6 +135,7 @@ def _run_step(case, shard, steps=2):
         tr.set_noise([torch.from_numpy(n[shard]) for n in noises])
         trainer.step(t(states), t(rewards), t(dones), oh, 0.5, it + 1, actions[shard],
                      disc_noise=None if dnoise is None else torch.from_numpy(dnoise[shard]))
+    os.environ.pop("SCM_BATCHED_HEADS", None)
     grads = torch.cat([f.flat.clone() for f in trainer.flats]) / trainer.world
     weights = torch.cat([p.detach().flatten() for m in (enc, dec, tr, rp, disc) for p in m.parameters()])
     return grads, weights, trainer.sync.hook_fired, trainer
@@ -141,19 +144,21 @@ def _run_step(case, shard, steps=2):
 def _trainer_worker(rank, world, port, case, out):
     _init(rank, world, port)
     half = B // world
-    grads, weights, fired, trainer = _run_step(case, slice(rank * half, (rank + 1) * half))
+    # (case "batched": the two ranks run the time-batched heads, the one-process reference below the per-step launches)
+    grads, weights, fired, trainer = _run_step("default" if case == "batched" else case,
+                                               slice(rank * half, (rank + 1) * half), batched_heads=case == "batched")
     out[rank] = (grads, weights, fired, trainer.sync.enabled)
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case", ["default", "lo", "gan", "no_overlap"])
+@pytest.mark.parametrize("case", ["default", "lo", "gan", "no_overlap", "batched"])
 def test_trainer_step_two_ranks_equal_full_batch(case):
     _paths()
     world = 2
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_trainer_worker, args=(world, _port(), case, out), nprocs=world, join=True)
-    ref_g, ref_w, fired, trainer = _run_step(case, slice(0, B))       # one process, the full batch
+    ref_g, ref_w, fired, trainer = _run_step("default" if case == "batched" else case, slice(0, B))   # one process, the full batch
     assert not trainer.sync.enabled and fired == 0                     # no collective without a process group
     for r in range(world):
         g, w, fired, enabled = out[r]

@@ -2,8 +2,13 @@
 // of one mid-grid workgroup of a cin -> 128, 64 x 64 x 64 convolution: ticks of prologue / K loop / epilogue.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DWINO_TIMING=300 -I scm_gan_amd/csrc -I include tools/exp/wino_phases.hip \
 //         -o tools/exp/bin/wino_phases
+#ifdef WINO_SRC            // (A/B against another revision of the kernel file: -DWINO_SRC='"bin/wino_old.hip"')
+#include WINO_SRC
+#else
 #include "../../scm_gan_amd/csrc/conv3x3_wino.hip"
-#include "../../scm_gan_amd/csrc/conv3x3_wino16.hip"      // (the entry point dispatches the 16-channel form)
+#endif
+#include "../../scm_gan_amd/csrc/conv3x3_wino16.hip"      // (the entry point dispatches the 16-channel forms)
+#include "../../scm_gan_amd/csrc/conv3x3_wino_k16.hip"
 #include <cstdio>
 #include <algorithm>
 #include <map>
