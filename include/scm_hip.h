@@ -405,6 +405,8 @@ typedef struct scm_decoder_fused_desc {
     float* workspace;
     int32_t B; int32_t H; int32_t W; int32_t C;
     int32_t loss_kind;
+    float* h_save;           /* optional [B][64][H][W]: the forward keeps its hidden map (leaky_relu applied, zero outside the
+                              * image) for scm_decoder_fused_bwd, which then does not recompute it; NULL: not written */
 } scm_decoder_fused_desc;
 
 size_t scm_decoder_fused_pack_floats(void);
@@ -428,6 +430,7 @@ typedef struct scm_decoder_fused_bwd_desc {
     int32_t B; int32_t H; int32_t W; int32_t C;
     int32_t loss_kind;       /* 0 BCE, 1 squared error */
     int32_t accumulate;
+    const float* h_saved;    /* the forward's h_save of the same z and pack, or NULL (the hidden map is recomputed from z) */
 } scm_decoder_fused_bwd_desc;
 
 int scm_decoder_fused_bwd(const scm_decoder_fused_bwd_desc* d, void* stream);
@@ -446,10 +449,13 @@ size_t scm_reward_fused_pack_floats(void);
 int scm_reward_fused_pack(const float* conv1_weight, const float* conv1_bias, const float* conv2_weight,
                           const float* conv2_bias, int latent, int Q, float* pack, void* stream);
 int scm_reward_fused_workspace(int B, int H, int W, int Q, size_t* bwd_floats);
-int scm_reward_fused_fwd(const float* z, const float* pack, float* o, int B, int H, int W, int Q, void* stream);
-int scm_reward_fused_bwd(const float* z, const float* pack, const float* d_o, float* dz, float* d_conv1_weight,
-                         float* d_conv1_bias, float* d_conv2_weight, float* d_conv2_bias, float* workspace, int B, int H,
-                         int W, int Q, int accumulate, void* stream);
+/* h_save (fwd, optional): [B][32][H][W], the hidden map in same-size coordinates (leaky_relu applied), kept for the
+ * backward pass; h_saved (bwd, optional): that buffer -- the backward then does not recompute conv1; NULL: recomputed. */
+int scm_reward_fused_fwd(const float* z, const float* pack, float* o, float* h_save, int B, int H, int W, int Q,
+                         void* stream);
+int scm_reward_fused_bwd(const float* z, const float* pack, const float* d_o, const float* h_saved, float* dz,
+                         float* d_conv1_weight, float* d_conv1_bias, float* d_conv2_weight, float* d_conv2_bias,
+                         float* workspace, int B, int H, int W, int Q, int accumulate, void* stream);
 
 #ifdef __cplusplus
 }

@@ -73,7 +73,7 @@ class DecoderFusedDesc(ctypes.Structure):
     _fields_ = [("z", ctypes.c_void_p), ("pack", ctypes.c_void_p), ("target", ctypes.c_void_p),
                 ("logits", ctypes.c_void_p), ("loss", ctypes.c_void_p), ("workspace", ctypes.c_void_p),
                 ("B", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32), ("C", ctypes.c_int32),
-                ("loss_kind", ctypes.c_int32)]
+                ("loss_kind", ctypes.c_int32), ("h_save", ctypes.c_void_p)]
 
 
 class DecoderFusedBwdDesc(ctypes.Structure):
@@ -83,7 +83,7 @@ class DecoderFusedBwdDesc(ctypes.Structure):
                 ("d_conv1_weight", ctypes.c_void_p), ("d_conv1_bias", ctypes.c_void_p),
                 ("d_conv2_weight", ctypes.c_void_p), ("d_conv2_bias", ctypes.c_void_p), ("workspace", ctypes.c_void_p),
                 ("B", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32), ("C", ctypes.c_int32),
-                ("loss_kind", ctypes.c_int32), ("accumulate", ctypes.c_int32)]
+                ("loss_kind", ctypes.c_int32), ("accumulate", ctypes.c_int32), ("h_saved", ctypes.c_void_p)]
 
 
 class CsrnDesc(ctypes.Structure):
@@ -165,8 +165,8 @@ def lib():
             "scm_reward_fused_pack_floats": [],
             "scm_reward_fused_pack": [vp, vp, vp, vp, ci, ci, vp, vp],
             "scm_reward_fused_workspace": [ci, ci, ci, ci, vp],
-            "scm_reward_fused_fwd": [vp, vp, vp, ci, ci, ci, ci, vp],
-            "scm_reward_fused_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp],
+            "scm_reward_fused_fwd": [vp, vp, vp, vp, ci, ci, ci, ci, vp],
+            "scm_reward_fused_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp],
         }
         for name, args in sigs.items():
             fn = getattr(L, name)      # raises AttributeError when the library lacks a declared symbol

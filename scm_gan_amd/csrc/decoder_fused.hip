@@ -156,6 +156,7 @@ static void df_geom_bwd(int B, int H, int W, int C, DecGeom* g) {
 struct DecFwdArgs {
     const float* z; const float* pack; const float* target; float* logits; float* loss_part;
     DecGeom g; int loss_kind;      // -1 none, 0 BCE, 1 squared error
+    float* hsave;                  // optional [B][64][H][W]: the hidden map, kept for the backward pass (which then skips GEMM1)
 };
 
 #define DF_FWD_LDS_FLOATS (DF_LAT * 3 * DF_ZS + 2 * 32 * 64 + 4)
@@ -282,6 +283,16 @@ __global__ void __launch_bounds__(256, 2) decoder_fused_fwd_kernel(const DecFwdA
             }
 #pragma unroll
             for (int j = 0; j < 16; ++j) d2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w2a[j], acc[j], d2, 0, 0, 0);
+            // the hidden row for the backward pass: every (row, column) is written by the band / column tile that owns it
+            // (register j of a lane half = one channel, its 32 lanes = 128 contiguous bytes)
+            if (a.hsave && r >= y0 && r < y1) {
+                const int hcol = c0 + gp * 32 + n;
+                if (hcol >= own_lo && hcol < own_hi) {
+                    float* hp = a.hsave + ((size_t)b * DF_HID + mt * 32 + 4 * hh) * plane + (size_t)r * g.W + hcol;
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) hp[(size_t)((j & 3) + 8 * (j >> 2)) * plane] = acc[j];
+                }
+            }
         }
         __syncthreads();                                // z slots and pbuf of the previous row are free
         if (row_in) {
@@ -367,7 +378,7 @@ extern "C" int scm_decoder_fused_fwd(const scm_decoder_fused_desc* d, void* stre
     SCM_REQUIRE(d->logits || d->loss_kind >= 0, "scm_decoder_fused_fwd: nothing to compute");
     DecFwdArgs a;
     a.z = d->z; a.pack = d->pack; a.target = d->loss_kind >= 0 ? d->target : nullptr; a.logits = d->logits;
-    a.loss_part = d->workspace; a.loss_kind = d->loss_kind;
+    a.loss_part = d->workspace; a.loss_kind = d->loss_kind; a.hsave = d->h_save;
     df_geom(d->B, d->H, d->W, d->C, &a.g);
     hipStream_t s = (hipStream_t)stream;
     const size_t lds = DF_FWD_LDS_FLOATS * sizeof(float);
@@ -402,6 +413,7 @@ struct DecBwdArgs {
     const float* z; const float* pack; const float* logits; const float* target; const float* gscale;
     float* dz; float* part;
     DecGeom g; int loss_kind; float inv_n;
+    const float* hsaved;           // HS = 1: the hidden map the forward pass kept ([B][64][H][W]); GEMM1 is not repeated
 };
 
 #define DB_ZS 72
@@ -418,6 +430,7 @@ struct DecBwdArgs {
 
 __device__ __forceinline__ int slot4(int r) { return (r + 4) & 3; }
 
+template <int HS>
 __global__ void __launch_bounds__(256, 1) decoder_fused_bwd_kernel(const DecBwdArgs a) {
     extern __shared__ float lds[];
     float* w1q = lds + DB_OFF_W1Q;
@@ -442,13 +455,15 @@ __global__ void __launch_bounds__(256, 1) decoder_fused_bwd_kernel(const DecBwdA
     const int C9 = 9 * g.C;
 
     // ---- resident operands
-    float wa[72], w2d[14], b1r[16];
+    float wa[HS ? 1 : 72], w2d[14], b1r[HS ? 1 : 16];
+    if constexpr (!HS) {
 #pragma unroll
-    for (int s = 0; s < 72; ++s) wa[s] = a.pack[DF_OFF_W1P + s * 128 + mt * 64 + lane];
+        for (int s = 0; s < 72; ++s) wa[s] = a.pack[DF_OFF_W1P + s * 128 + mt * 64 + lane];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) b1r[j] = a.pack[DF_OFF_B1 + mt * 32 + acc_row(j, hh)];
+    }
 #pragma unroll
     for (int s = 0; s < 14; ++s) w2d[s] = a.pack[DF_OFF_W2D + (mt * 14 + s) * 64 + lane];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) b1r[j] = a.pack[DF_OFF_B1 + mt * 32 + acc_row(j, hh)];
     {
         const f32x4* src = reinterpret_cast<const f32x4*>(a.pack + DF_OFF_W1Q);
         f32x4* dst = reinterpret_cast<f32x4*>(w1q);
@@ -561,17 +576,37 @@ __global__ void __launch_bounds__(256, 1) decoder_fused_bwd_kernel(const DecBwdA
     const int ocol = c0 + ox;
     const bool ocolown = ocol >= own_lo && ocol < own_hi;
 
+    // HS: this lane's 16 channels of hidden row rr at its pixel, requested one row ahead (zero outside the image, as
+    // the forward pass wrote conv2's zero padding)
+    float hcur[HS ? 16 : 1], hnext[HS ? 16 : 1];
+    auto h_load = [&](int rr, float* v) {
+        if constexpr (HS) {
+            const int hcol = c0 + gp * 32 + n;
+            const bool ok = rr >= 0 && rr < g.H && hcol < g.W;
+            const float* hp = a.hsaved + ((size_t)b * DF_HID + mt * 32 + 4 * hh) * plane + (size_t)(ok ? rr : 0) * g.W +
+                              (ok ? hcol : 0);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float x = hp[(size_t)((j & 3) + 8 * (j >> 2)) * plane];
+                v[j] = ok ? x : 0.f;
+            }
+        }
+    };
+    h_load(y0 - 1, hcur);
+
     for (int r = y0 - 1; r <= y1; ++r) {
         const bool row_in = r >= 0 && r < g.H;
         const bool row_own = r >= y0 && r < y1;
         float zv[DF_ZL], lgv, tgv;
         z_load(r + 2, zv);
         dl_load(r + 2, &lgv, &tgv);
+        h_load(r + 1, hnext);
         // LDS row offsets of image rows r-1, r, r+1 (and 0 for the constant regions)
         const int ro0 = slot4(r - 1) * DB_ZS, ro1 = slot4(r) * DB_ZS, ro2 = slot4(r + 1) * DB_ZS;
 
         f32x16 hacc = {0}, dh = {0};
         if (row_in) {
+            if constexpr (!HS) {
             // ---- GEMM1: h row r
             const float* zb0 = zrow + hh * 4 * DB_ZS + gp * 32 + n;
             float bq[9], bn[9];
@@ -597,6 +632,7 @@ __global__ void __launch_bounds__(256, 1) decoder_fused_bwd_kernel(const DecBwdA
 #pragma unroll
                 for (int t = 0; t < 9; ++t) bq[t] = bn[t];
             }
+            }
             // ---- dh = lrelu'(h) . (W2c^T dl): K = (c,tap) pairs 2s + hh
             float bd[14];
 #pragma unroll
@@ -614,9 +650,16 @@ __global__ void __launch_bounds__(256, 1) decoder_fused_bwd_kernel(const DecBwdA
             const bool hown = row_own && hcol >= own_lo && hcol < own_hi;
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const float pre = hacc[j] + b1r[j];
-                const float hv = colok ? (pre > 0.f ? pre : 0.01f * pre) : 0.f;
-                const float dv = colok ? dh[j] * (pre > 0.f ? 1.f : 0.01f) : 0.f;
+                float hv, dv;
+                if constexpr (HS) {
+                    // (leaky_relu keeps the sign: the saved activation is its own gate; zero where the forward masked it)
+                    hv = hcur[j];
+                    dv = colok ? dh[j] * (hv > 0.f ? 1.f : 0.01f) : 0.f;
+                } else {
+                    const float pre = hacc[j] + b1r[j];
+                    hv = colok ? (pre > 0.f ? pre : 0.01f * pre) : 0.f;
+                    dv = colok ? dh[j] * (pre > 0.f ? 1.f : 0.01f) : 0.f;
+                }
                 hacc[j] = hv;
                 dh[j] = dv;
                 // [channel][pixel] images for the products that contract over pixels
@@ -624,6 +667,10 @@ __global__ void __launch_bounds__(256, 1) decoder_fused_bwd_kernel(const DecBwdA
                 hT[o] = hv;
                 dhT[o] = hown ? dv : 0.f;
             }
+        }
+        if constexpr (HS) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) hcur[j] = hnext[j];
         }
         z_store(r + 2, zv);
         dl_store(r + 2, lgv, tgv);
@@ -833,15 +880,21 @@ extern "C" int scm_decoder_fused_bwd(const scm_decoder_fused_bwd_desc* d, void* 
                 "scm_decoder_fused_bwd: null output");
     DecBwdArgs a;
     a.z = d->z; a.pack = d->pack; a.logits = d->logits; a.target = d->target; a.gscale = d->g_loss;
-    a.dz = d->dz; a.part = d->workspace; a.loss_kind = d->loss_kind;
+    a.dz = d->dz; a.part = d->workspace; a.loss_kind = d->loss_kind; a.hsaved = d->h_saved;
     a.inv_n = 1.f / ((float)d->C * d->H * d->W);
     df_geom_bwd(d->B, d->H, d->W, d->C, &a.g);
     hipStream_t s = (hipStream_t)stream;
     const size_t lds = DB_LDS_FLOATS * sizeof(float);
     static std::atomic<uint64_t> attr_done{0};
-    if (int rc = scm_ensure_lds_attr(reinterpret_cast<const void*>(decoder_fused_bwd_kernel), attr_done, (int)lds)) return rc;
+    static std::atomic<uint64_t> attr_done_hs{0};
     const int wgs = d->B * a.g.nxt * a.g.nbands;
-    hipLaunchKernelGGL(decoder_fused_bwd_kernel, dim3(wgs), dim3(256), lds, s, a);
+    if (d->h_saved) {
+        if (int rc = scm_ensure_lds_attr(reinterpret_cast<const void*>(decoder_fused_bwd_kernel<1>), attr_done_hs, (int)lds)) return rc;
+        hipLaunchKernelGGL(decoder_fused_bwd_kernel<1>, dim3(wgs), dim3(256), lds, s, a);
+    } else {
+        if (int rc = scm_ensure_lds_attr(reinterpret_cast<const void*>(decoder_fused_bwd_kernel<0>), attr_done, (int)lds)) return rc;
+        hipLaunchKernelGGL(decoder_fused_bwd_kernel<0>, dim3(wgs), dim3(256), lds, s, a);
+    }
     SCM_LAUNCH_CHECK("decoder_fused_bwd_kernel");
     const int total = 64 * 144 + 64 + 64 * 9 * d->C + d->C;
     hipLaunchKernelGGL(decoder_fused_wgrad_reduce_kernel, dim3((total + 31) / 32), dim3(256), 0, s, d->workspace, wgs,

@@ -103,6 +103,7 @@ static int rf_geom(int B, int H, int W, int Q, int min_wgs, RewGeom* g) {
 // ----------------------------------------------------------------------------------------- forward
 struct RewFwdArgs {
     const float* z; const float* pack; float* o; RewGeom g;
+    float* hsave;       // optional [B][32][H][W]: the hidden map in same-size coordinates, kept for the backward pass
 };
 #define RF_FWD_LDS_FLOATS (RF_LAT * 3 * RF_ZS + 64 * 64)
 
@@ -219,6 +220,12 @@ __global__ void __launch_bounds__(RF_NT, 2) reward_fused_fwd_kernel(const RewFwd
                 d2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2a[0][j], acc[j], d2[0], 0, 0, 0);
                 d2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2a[1][j], acc[j], d2[1], 0, 0, 0);
             }
+            // the hidden row for the backward pass (written by the band that owns the row)
+            if (a.hsave && r >= y0 && r < y1 && colok) {
+                float* hp = a.hsave + ((size_t)b * RF_HID + 4 * hh) * plane + (size_t)r * g.W + gp * 32 + n;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) hp[(size_t)((j & 3) + 8 * (j >> 2)) * plane] = acc[j];
+            }
         }
         __syncthreads();
         if (row_in) {
@@ -258,6 +265,7 @@ __global__ void __launch_bounds__(RF_NT, 2) reward_fused_fwd_kernel(const RewFwd
 #define RF_BWD_PART (32 * 160 + 32 * 64 + 8)
 struct RewBwdArgs {
     const float* z; const float* pack; const float* d_o; float* dz; float* part; RewGeom g;
+    const float* hsaved;        // HS = 1: the forward's hidden map; conv1 is not repeated
 };
 #define RB_OFF_W1Q 0                                   // 5120
 #define RB_OFF_Z (RB_OFF_W1Q + 5120)                   // [16][4][RF_ZS]
@@ -271,6 +279,7 @@ struct RewBwdArgs {
 #define RF_DL_N (6 * 66)
 #define RF_DLL ((RF_DL_N + RF_NT - 1) / RF_NT)
 
+template <int HS>
 __global__ void __launch_bounds__(RF_NT, 1) reward_fused_bwd_kernel(const RewBwdArgs a) {
     extern __shared__ float lds[];
     float* w1q = lds + RB_OFF_W1Q;
@@ -289,13 +298,15 @@ __global__ void __launch_bounds__(RF_NT, 1) reward_fused_bwd_kernel(const RewBwd
     const float* zb = a.z + (size_t)b * RF_LAT * plane;
     const int C9 = 9 * g.Q;
 
-    float wa[72], w2d[27], b1r[16];
+    float wa[HS ? 1 : 72], w2d[27], b1r[HS ? 1 : 16];
+    if constexpr (!HS) {
 #pragma unroll
-    for (int s = 0; s < 72; ++s) wa[s] = a.pack[RF_OFF_W1P + s * 64 + lane];
+        for (int s = 0; s < 72; ++s) wa[s] = a.pack[RF_OFF_W1P + s * 64 + lane];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) b1r[j] = a.pack[RF_OFF_B1 + rf_acc_row(j, hh)];
+    }
 #pragma unroll
     for (int s = 0; s < 27; ++s) w2d[s] = a.pack[RF_OFF_W2D + s * 64 + lane];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) b1r[j] = a.pack[RF_OFF_B1 + rf_acc_row(j, hh)];
     {
         const f32x4* src = reinterpret_cast<const f32x4*>(a.pack + RF_OFF_W1Q);
         f32x4* dst = reinterpret_cast<f32x4*>(w1q);
@@ -415,15 +426,34 @@ __global__ void __launch_bounds__(RF_NT, 1) reward_fused_bwd_kernel(const RewBwd
             for (int k = 0; k < 3; ++k) V[i][c][k] = 0.f;
     const int ox = tid & 63, ocq = tid >> 6;
 
+    // HS: this lane's 16 channels of hidden row rr at its pixel, requested one row ahead (zero outside the frame, as the
+    // forward pass masked them)
+    float hcur[HS ? 16 : 1], hnext[HS ? 16 : 1];
+    auto h_load = [&](int rr, float* v) {
+        if constexpr (HS) {
+            const int hcol = gp * 32 + n;
+            const bool ok = rr >= 0 && rr < g.H && hcol < g.W;
+            const float* hp = a.hsaved + ((size_t)b * RF_HID + 4 * hh) * plane + (size_t)(ok ? rr : 0) * g.W + (ok ? hcol : 0);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float x = hp[(size_t)((j & 3) + 8 * (j >> 2)) * plane];
+                v[j] = ok ? x : 0.f;
+            }
+        }
+    };
+    h_load(y0 - 1, hcur);
+
     for (int r = y0 - 1; r <= y1; ++r) {
         const bool row_in = r >= 0 && r < g.H;
         const bool row_own = r >= y0 && r < y1;
         float zv[RF_ZL], dv4[RF_DLL];
         z_load(r + 2, zv);
         dl_load(r + 2, dv4);
+        h_load(r + 1, hnext);
         const int ro0 = rf_slot4(r - 1) * RF_ZS, ro1 = rf_slot4(r) * RF_ZS, ro2 = rf_slot4(r + 1) * RF_ZS;
         f32x16 hacc = {0}, dh = {0};
         if (row_in) {
+            if constexpr (!HS) {
             const float* zb0 = zrow + hh * 4 * RF_ZS + gp * 32 + n;
             float bq[9], bn[9];
 #pragma unroll
@@ -448,6 +478,7 @@ __global__ void __launch_bounds__(RF_NT, 1) reward_fused_bwd_kernel(const RewBwd
 #pragma unroll
                 for (int t = 0; t < 9; ++t) bq[t] = bn[t];
             }
+            }
             float bd[27];
 #pragma unroll
             for (int s = 0; s < 27; ++s) {
@@ -463,15 +494,25 @@ __global__ void __launch_bounds__(RF_NT, 1) reward_fused_bwd_kernel(const RewBwd
             const bool colok = hcol < g.W;
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const float pre = hacc[j] + b1r[j];
-                const float hv = colok ? (pre > 0.f ? pre : 0.01f * pre) : 0.f;
-                const float dv = colok ? dh[j] * (pre > 0.f ? 1.f : 0.01f) : 0.f;
+                float hv, dv;
+                if constexpr (HS) {
+                    hv = hcur[j];           // (leaky_relu keeps the sign: the saved activation is its own gate)
+                    dv = colok ? dh[j] * (hv > 0.f ? 1.f : 0.01f) : 0.f;
+                } else {
+                    const float pre = hacc[j] + b1r[j];
+                    hv = colok ? (pre > 0.f ? pre : 0.01f * pre) : 0.f;
+                    dv = colok ? dh[j] * (pre > 0.f ? 1.f : 0.01f) : 0.f;
+                }
                 hacc[j] = hv;
                 dh[j] = dv;
                 const int o = rf_acc_row(j, hh) * 65 + gp * 32 + n;
                 hT[o] = hv;
                 dhT[o] = row_own ? dv : 0.f;
             }
+        }
+        if constexpr (HS) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) hcur[j] = hnext[j];
         }
         z_store(r + 2, zv);
         dl_store(r + 2, dv4);
@@ -673,10 +714,11 @@ extern "C" int scm_reward_fused_workspace(int B, int H, int W, int Q, size_t* bw
     return SCM_OK;
 }
 
-extern "C" int scm_reward_fused_fwd(const float* z, const float* pack, float* o, int B, int H, int W, int Q, void* stream) {
+extern "C" int scm_reward_fused_fwd(const float* z, const float* pack, float* o, float* h_save, int B, int H, int W, int Q,
+                                    void* stream) {
     SCM_REQUIRE(z && pack && o && B > 0 && Q >= 1 && Q <= 6, "scm_reward_fused_fwd: bad arguments");
     RewFwdArgs a;
-    a.z = z; a.pack = pack; a.o = o;
+    a.z = z; a.pack = pack; a.o = o; a.hsave = h_save;
     if (!rf_geom(B, H, W, Q, 1024, &a.g)) {
         scm_set_error("scm_reward_fused_fwd: frames must be 5..64 wide and at least 5 high (got %dx%d)", H, W);
         return SCM_EUNSUPPORTED;
@@ -689,13 +731,13 @@ extern "C" int scm_reward_fused_fwd(const float* z, const float* pack, float* o,
     return SCM_OK;
 }
 
-extern "C" int scm_reward_fused_bwd(const float* z, const float* pack, const float* d_o, float* dz, float* d_conv1_weight,
-                                    float* d_conv1_bias, float* d_conv2_weight, float* d_conv2_bias, float* workspace,
-                                    int B, int H, int W, int Q, int accumulate, void* stream) {
+extern "C" int scm_reward_fused_bwd(const float* z, const float* pack, const float* d_o, const float* h_saved, float* dz,
+                                    float* d_conv1_weight, float* d_conv1_bias, float* d_conv2_weight, float* d_conv2_bias,
+                                    float* workspace, int B, int H, int W, int Q, int accumulate, void* stream) {
     SCM_REQUIRE(z && pack && d_o && dz && d_conv1_weight && d_conv1_bias && d_conv2_weight && d_conv2_bias && workspace &&
                     B > 0 && Q >= 1 && Q <= 6, "scm_reward_fused_bwd: bad arguments");
     RewBwdArgs a;
-    a.z = z; a.pack = pack; a.d_o = d_o; a.dz = dz; a.part = workspace;
+    a.z = z; a.pack = pack; a.d_o = d_o; a.dz = dz; a.part = workspace; a.hsaved = h_saved;
     if (!rf_geom(B, H, W, Q, 512, &a.g)) {
         scm_set_error("scm_reward_fused_bwd: frames must be 5..64 wide and at least 5 high (got %dx%d)", H, W);
         return SCM_EUNSUPPORTED;
@@ -703,9 +745,15 @@ extern "C" int scm_reward_fused_bwd(const float* z, const float* pack, const flo
     hipStream_t s = (hipStream_t)stream;
     const size_t lds = RB_LDS_FLOATS * sizeof(float);
     static std::atomic<uint64_t> attr_done{0};
-    if (int rc = scm_ensure_lds_attr(reinterpret_cast<const void*>(reward_fused_bwd_kernel), attr_done, (int)lds)) return rc;
+    static std::atomic<uint64_t> attr_done_hs{0};
     const int wgs = B * a.g.nbands;
-    hipLaunchKernelGGL(reward_fused_bwd_kernel, dim3(wgs), dim3(RF_NT), lds, s, a);
+    if (h_saved) {
+        if (int rc = scm_ensure_lds_attr(reinterpret_cast<const void*>(reward_fused_bwd_kernel<1>), attr_done_hs, (int)lds)) return rc;
+        hipLaunchKernelGGL(reward_fused_bwd_kernel<1>, dim3(wgs), dim3(RF_NT), lds, s, a);
+    } else {
+        if (int rc = scm_ensure_lds_attr(reinterpret_cast<const void*>(reward_fused_bwd_kernel<0>), attr_done, (int)lds)) return rc;
+        hipLaunchKernelGGL(reward_fused_bwd_kernel<0>, dim3(wgs), dim3(RF_NT), lds, s, a);
+    }
     SCM_LAUNCH_CHECK("reward_fused_bwd_kernel");
     const int total = 32 * 144 + 32 + 32 * 9 * Q + Q;
     hipLaunchKernelGGL(reward_fused_wgrad_reduce_kernel, dim3((total + 31) / 32), dim3(256), 0, s, workspace, wgs, Q, accumulate,

@@ -837,7 +837,12 @@ def _decoder_fused_ws(B, H, W, C):
     return f.value, b.value
 
 
-def decoder_fused_fwd(z, pack, C, target=None, loss_kind=-1, want_logits=True):
+# The fused heads keep their hidden maps (64 / 32 channels) for the backward pass, which then skips recomputing them:
+# a quarter of its MFMAs.  SCM_NO_SAVED_HIDDEN=1: recompute from z (round 2's form; the A/B).
+save_hidden = os.environ.get("SCM_NO_SAVED_HIDDEN", "0") in ("", "0")
+
+
+def decoder_fused_fwd(z, pack, C, target=None, loss_kind=-1, want_logits=True, h_save=None):
     """(logits or None, per-sample loss or None) of the fused decoder forward (no autograd)."""
     z = _chk(z, "decoder_fused")
     target = _chk(target, "decoder_fused")
@@ -845,7 +850,7 @@ def decoder_fused_fwd(z, pack, C, target=None, loss_kind=-1, want_logits=True):
     logits = _new(z, B, C, H, W) if want_logits else None
     loss = _new(z, B) if loss_kind >= 0 else None
     ws = _new(z, max(1, _decoder_fused_ws(B, H, W, C)[0])) if loss_kind >= 0 else None
-    d = L.DecoderFusedDesc(_p(z), _p(pack), _p(target), _p(logits), _p(loss), _p(ws), B, H, W, C, loss_kind)
+    d = L.DecoderFusedDesc(_p(z), _p(pack), _p(target), _p(logits), _p(loss), _p(ws), B, H, W, C, loss_kind, _p(h_save))
     if kernel_timer is not None:
         ev = kernel_timer.bracket("decoder_fused_fwd", 2.0 * B * H * W * 9 * (16 * 64 + 64 * C))
         ev[0].record()
@@ -866,17 +871,18 @@ class DecoderLossFn(Function):
         z = _chk(z, "decoder_loss")
         target = _chk(target, "decoder_loss")
         C = target.shape[1]
-        logits, loss = decoder_fused_fwd(z, pack, C, target, kind, True)
+        hid = _new(z, z.shape[0], 64, z.shape[2], z.shape[3]) if (save_hidden and any(ctx.needs_input_grad)) else None
+        logits, loss = decoder_fused_fwd(z, pack, C, target, kind, True, hid)
         ctx.kind, ctx.C = kind, C
         ctx.params = (w1, b1, w2, b2)
-        ctx.save_for_backward(z, target, logits, pack)
+        ctx.save_for_backward(z, target, logits, pack, hid)
         ctx.mark_non_differentiable(logits)
         ctx.set_materialize_grads(False)
         return loss, logits
 
     @staticmethod
     def backward(ctx, g_loss, _g_logits):
-        z, target, logits, pack = ctx.saved_tensors
+        z, target, logits, pack, hid = ctx.saved_tensors
         g_loss = _chk(g_loss, "decoder_loss.backward")
         B, _, H, W = z.shape
         C = ctx.C
@@ -887,7 +893,7 @@ class DecoderLossFn(Function):
         dz = torch.empty_like(z)
         ws = _new(z, max(1, _decoder_fused_ws(B, H, W, C)[1]))
         d = L.DecoderFusedBwdDesc(_p(z), _p(pack), _p(logits), _p(target), _p(g_loss), _p(dz), _p(grads[0]), _p(grads[1]),
-                                  _p(grads[2]), _p(grads[3]), _p(ws), B, H, W, C, ctx.kind, 1 if acc else 0)
+                                  _p(grads[2]), _p(grads[3]), _p(ws), B, H, W, C, ctx.kind, 1 if acc else 0, _p(hid))
         if kernel_timer is not None:
             ev = kernel_timer.bracket("decoder_fused_bwd", 2.0 * B * H * W * 9 * (4 * 16 * 64 + 2 * 64 * C))
             ev[0].record()
@@ -922,16 +928,17 @@ class RewardConvFn(Function):
         if kernel_timer is not None:
             ev = kernel_timer.bracket("reward_fused_fwd", 2.0 * B * 9 * ((H - 2) * (W - 2) * 16 * 32 + o.shape[2] * o.shape[3] * 32 * Q))
             ev[0].record()
-        L.check(L.lib().scm_reward_fused_fwd(_p(z), _p(pack), _p(o), B, H, W, Q, _stream()), "scm_reward_fused_fwd")
+        hid = _new(z, B, 32, H, W) if (save_hidden and any(ctx.needs_input_grad)) else None
+        L.check(L.lib().scm_reward_fused_fwd(_p(z), _p(pack), _p(o), _p(hid), B, H, W, Q, _stream()), "scm_reward_fused_fwd")
         if kernel_timer is not None:
             ev[1].record()
         ctx.params = (w1, b1, w2, b2)
-        ctx.save_for_backward(z, pack)
+        ctx.save_for_backward(z, pack, hid)
         return o
 
     @staticmethod
     def backward(ctx, g_o):
-        z, pack = ctx.saved_tensors
+        z, pack, hid = ctx.saved_tensors
         g_o = _chk(g_o, "reward_conv.backward")
         B, _, H, W = z.shape
         Q = g_o.shape[1]
@@ -942,7 +949,7 @@ class RewardConvFn(Function):
         n = ctypes.c_size_t()
         L.check(L.lib().scm_reward_fused_workspace(B, H, W, Q, ctypes.byref(n)), "scm_reward_fused_workspace")
         ws = _new(z, max(1, n.value))
-        L.check(L.lib().scm_reward_fused_bwd(_p(z), _p(pack), _p(g_o), _p(dz), _p(grads[0]), _p(grads[1]), _p(grads[2]),
+        L.check(L.lib().scm_reward_fused_bwd(_p(z), _p(pack), _p(g_o), _p(hid), _p(dz), _p(grads[0]), _p(grads[1]), _p(grads[2]),
                                              _p(grads[3]), _p(ws), B, H, W, Q, 1 if acc else 0, _stream()),
                 "scm_reward_fused_bwd")
         if acc:
