@@ -50,5 +50,5 @@ if not commit:
     except OSError:
         commit = None
 json.dump({'kernel_source_sha16': sha, 'git_commit': os.environ.get('SCM_GIT_COMMIT') or commit, 'source': 'rocprofv3 --kernel-trace --pmc <FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE> -- python3 tools/prof_hot2.py (separate passes)',
-           'case': '128->128 channels, B=64, 64x64, circular padding, leaky-relu, 1-bit gate mask: forward, gated dgrad, wgrad; fp32 Winograd F(2x2,3x3) (the default), fp32 direct, fp32-on-the-bf16-pipe (x3) and 16-bit-operand kernels; fused decoder + BCE forward / backward at B=64, 64x64x3; since round 3 also the producer-gated Winograd forms (ungated weight gradient <0,1,0>) and the 16-channel-side layers of the transition (conv6 forward 256->16, its weight gradient and its input gradient 16->256, conv1 forward and weight gradient 16<->128); last dispatch of each kernel',
+           'case': '128->128 channels, B=64, 64x64, circular padding, leaky-relu, 1-bit gate mask: forward, gated dgrad, wgrad; fp32 Winograd F(2x2,3x3) (the default), fp32 direct, fp32-on-the-bf16-pipe (x3) and 16-bit-operand kernels; fused decoder + BCE: backward (with the kept hidden map) over the 512 samples of a time-batched iteration, forward as inference launches it at B=64, 64x64x3; fused reward head forward / backward at 512 samples; since round 3 also the producer-gated Winograd forms (ungated weight gradient <0,1,0>) and the 16-channel-side layers of the transition (conv6 forward 256->16, its weight gradient and its input gradient 16->256, conv1 forward and weight gradient 16<->128); last dispatch of each kernel',
            'kernels': out}, sys.stdout, indent=1)

@@ -69,15 +69,23 @@ for _ in range(3):
                      ymask1=mask, ymask2=mask)
     ops._conv3x3_raw(z16, None, None, None, 0, fp1[0], C, None, bias, None, C, 1, ops.ACT_LRELU, fp1[2], mask_out=mask)
 torch.cuda.synchronize()
-# the fused decoder + BCE launches of one unrolled step (fp32): forward, backward, at the bench batch
+# the fused decoder + BCE launches of one training iteration (fp32): forward (keeping the hidden map) and backward over
+# the 8 x 64 samples of all unrolled steps at once (time-batched heads, Trainer.step); then the forward as inference /
+# bench.py's decoder leg launches it (B = 64, no hidden map kept) -- the LAST dispatch of the forward kernel, the one
+# tools/pmc_parse.py records
 ops.set_compute_precision('fp32')
 ops.set_conv_algo('winograd')
 from scm_gan_amd import models as M
+NT = 8
 dec = M.Decoder(16, 3)
-z = (torch.rand(B, 16, H, W, device='cuda') < 0.5).float().requires_grad_(True)
-tgt = (torch.rand(B, 3, H, W, device='cuda') < 0.1).float()
+z = (torch.rand(NT * B, 16, H, W, device='cuda') < 0.5).float().requires_grad_(True)
+tgt = (torch.rand(NT * B, 3, H, W, device='cuda') < 0.1).float()
 for _ in range(3):
     dec.forward_loss(z, tgt).mean().backward()
+torch.cuda.synchronize()
+with torch.no_grad():
+    for _ in range(3):
+        dec.forward_loss(z[:B], tgt[:B])
 torch.cuda.synchronize()
 # the encoder's forward as the training step launches it (zero padding: conv1 9 -> 128 on the 16-input-channel kernel,
 # conv2 / conv3 on the wide kernel's zero-padded instantiation, conv4 128 -> 16 on the 16-row kernel) -- the north star's
@@ -87,9 +95,9 @@ xe = (torch.rand(B, 3, 3, H, W, device='cuda') < 0.1).float()
 for _ in range(3):
     enc(xe).sum().backward()
 torch.cuda.synchronize()
-# the fused reward head, forward + backward
+# the fused reward head, forward + backward, time-batched as the training iteration launches it (8 x 64 samples)
 rp = M.RewardPredictor(16, 2)
-zr = (torch.rand(B, 16, H, W, device='cuda') < 0.5).float().requires_grad_(True)
+zr = (torch.rand(NT * B, 16, H, W, device='cuda') < 0.5).float().requires_grad_(True)
 for _ in range(3):
     rp(zr).sum().backward()
 torch.cuda.synchronize()
