@@ -203,7 +203,7 @@ class RewardPredictor(nn.Module):
         if self._fused(x):
             # both convolutions in one pass over z (scm_reward_fused_*), the 32-channel map stays on chip
             x = ops.RewardConvFn.apply(x, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias,
-                                       self._fused_pack())
+                                       self._fused_pack(), torch.is_grad_enabled())
         elif x.shape[2] > 2 and x.shape[3] > 2:
             # conv1 (valid 3x3) = interior of the same-size conv on the MFMA kernel; conv2 reads that
             # interior in place (padding -1): no crop copy forward, no zero-embed backward
@@ -250,7 +250,7 @@ class Decoder(nn.Module):
         if not self._fused():
             return ops.PixelLossFn.apply(self.forward(z_map), target, kind)
         loss, _ = ops.DecoderLossFn.apply(z_map, target, self.conv1.weight, self.conv1.bias, self.conv2.weight,
-                                          self.conv2.bias, self._fused_pack(), kind)
+                                          self.conv2.bias, self._fused_pack(), kind, torch.is_grad_enabled())
         return loss
 
     def forward(self, z_map, visualize=False):

@@ -867,11 +867,12 @@ class DecoderLossFn(Function):
     recomputes it from z.  Returns (loss, logits); logits carry no gradient."""
 
     @staticmethod
-    def forward(ctx, z, target, w1, b1, w2, b2, pack, kind):
+    def forward(ctx, z, target, w1, b1, w2, b2, pack, kind, keep_hidden=True):
         z = _chk(z, "decoder_loss")
         target = _chk(target, "decoder_loss")
         C = target.shape[1]
-        hid = _new(z, z.shape[0], 64, z.shape[2], z.shape[3]) if (save_hidden and any(ctx.needs_input_grad)) else None
+        # (keep_hidden: the caller's torch.is_grad_enabled() -- inside forward() grad mode is always off)
+        hid = _new(z, z.shape[0], 64, z.shape[2], z.shape[3]) if (save_hidden and keep_hidden and any(ctx.needs_input_grad)) else None
         logits, loss = decoder_fused_fwd(z, pack, C, target, kind, True, hid)
         ctx.kind, ctx.C = kind, C
         ctx.params = (w1, b1, w2, b2)
@@ -901,8 +902,8 @@ class DecoderLossFn(Function):
         if kernel_timer is not None:
             ev[1].record()
         if acc:
-            return dz, None, None, None, None, None, None, None
-        return dz, None, grads[0], grads[1], grads[2], grads[3], None, None
+            return dz, None, None, None, None, None, None, None, None
+        return dz, None, grads[0], grads[1], grads[2], grads[3], None, None, None
 
 
 # ------------------------------------------------------ fused reward head
@@ -920,7 +921,7 @@ class RewardConvFn(Function):
     z (B, 16, H, W) -> o (B, 3R, OH, OW).  The hidden map is recomputed in backward."""
 
     @staticmethod
-    def forward(ctx, z, w1, b1, w2, b2, pack):
+    def forward(ctx, z, w1, b1, w2, b2, pack, keep_hidden=True):
         z = _chk(z, "reward_conv")
         B, _, H, W = z.shape
         Q = w2.shape[0]
@@ -928,7 +929,7 @@ class RewardConvFn(Function):
         if kernel_timer is not None:
             ev = kernel_timer.bracket("reward_fused_fwd", 2.0 * B * 9 * ((H - 2) * (W - 2) * 16 * 32 + o.shape[2] * o.shape[3] * 32 * Q))
             ev[0].record()
-        hid = _new(z, B, 32, H, W) if (save_hidden and any(ctx.needs_input_grad)) else None
+        hid = _new(z, B, 32, H, W) if (save_hidden and keep_hidden and any(ctx.needs_input_grad)) else None
         L.check(L.lib().scm_reward_fused_fwd(_p(z), _p(pack), _p(o), _p(hid), B, H, W, Q, _stream()), "scm_reward_fused_fwd")
         if kernel_timer is not None:
             ev[1].record()
@@ -953,8 +954,8 @@ class RewardConvFn(Function):
                                              _p(grads[3]), _p(ws), B, H, W, Q, 1 if acc else 0, _stream()),
                 "scm_reward_fused_bwd")
         if acc:
-            return dz, None, None, None, None, None
-        return dz, grads[0], grads[1], grads[2], grads[3], None
+            return dz, None, None, None, None, None, None
+        return dz, grads[0], grads[1], grads[2], grads[3], None, None
 
 
 _mean_weights = {}

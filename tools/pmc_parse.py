@@ -12,8 +12,11 @@ for f in glob.glob(os.path.join(root, '**', '*counter_collection.csv'), recursiv
     for (k, c), (_, v) in last.items():
         vals.setdefault(k, {})[c] = v
 for f in glob.glob(os.path.join(root, '**', '*kernel_trace.csv'), recursive=True):
+    per = {}
     for r in csv.DictReader(open(f)):
-        dur.setdefault(r['Kernel_Name'], []).append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
+        per.setdefault(r['Kernel_Name'], []).append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
+    for k, v in per.items():        # the last launch group of the pass: the shape the counters' (last) dispatch had
+        dur.setdefault(k, []).extend(v[-3:])
 out = {}
 for k, c in vals.items():
     if 'pack_' in k or not any(t in k for t in ('conv3x3_mfma', 'conv3x3_h16', 'conv3x3_x3', 'conv3x3_wgrad', 'conv3x3_wino', 'decoder_fused_fwd', 'decoder_fused_bwd', 'reward_fused', 'sn_power_iter')):
