@@ -31,8 +31,13 @@ __device__ __forceinline__ void wino16_mfma(f32x4& acc, float a, float b) {
     asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
 }
 
-template <int NJ, int PADC>
-__global__ void __launch_bounds__(256, 1) conv3x3_wino16_kernel(const ConvKArgs a) {
+// NB: 16-patch blocks per wave.  2: 16 co x 128 patches per workgroup, 128 accumulator registers + two sets of four
+// transformed patches (128 registers): one wave per SIMD.  1: 16 co x 64 patches, 64 + 64 registers: the kernel fits a
+// CU two or three times, and a workgroup that waits for its rows leaves the SIMD to another (these layers are bound by
+// memory latency and instruction issue, not by the MFMA pipe: PMC MFMA-busy 0.40 at one wave per SIMD).
+template <int NJ, int PADC, int NB>
+__global__ void __launch_bounds__(256, NB == 1 ? 2 : 1) conv3x3_wino16_kernel(const ConvKArgs a) {
+    constexpr int TILES = 64 * NB;                    // patches per workgroup
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int PLANE = NJ * 512;                   // floats per channel of the raw halo rows
     constexpr int RST = KC * PLANE;                   // one raw stage
@@ -51,9 +56,9 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino16_kernel(const ConvKArgs 
 
     int b, wt, cg_;
     scm_xcd_tile_map(a.B, a.tiles_per_img, b, wt, cg_);
-    const int t0 = wt * W16_TILES;
+    const int t0 = wt * TILES;
     const int ty0 = t0 / TCW;
-    int tlast = t0 + W16_TILES - 1;
+    int tlast = t0 + TILES - 1;
     if (tlast > ntiles - 1) tlast = ntiles - 1;
     const int nrows = 2 * (tlast / TCW - ty0) + 4;
     const int npair = nrows * HPR;
@@ -94,11 +99,11 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino16_kernel(const ConvKArgs 
     }
     // this lane's two patches (blocks 0 / 1 of the wave): offsets of their 4x4 input patches in a raw plane, and
     // their output positions
-    int traw[2], p00[2];
-    bool tval[2];
+    int traw[NB], p00[NB];
+    bool tval[NB];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int t = t0 + wave * 32 + 16 * k + l15;
+    for (int k = 0; k < NB; ++k) {
+        const int t = t0 + wave * (16 * NB) + 16 * k + l15;
         tval[k] = t < ntiles;
         const int tc = tval[k] ? t : ntiles - 1;
         const int ty = tc / TCW, tx = tc - ty * TCW;
@@ -106,11 +111,11 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino16_kernel(const ConvKArgs 
         p00[k] = 2 * ty * W + 2 * tx;
     }
 
-    f32x4 acc[16][2];
+    f32x4 acc[16][NB];
 #pragma unroll
     for (int f = 0; f < 16; ++f)
 #pragma unroll
-        for (int k = 0; k < 2; ++k) acc[f][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < NB; ++k) acc[f][k] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int cin = a.c1 + a.c2;
     const int nchunk = (cin + KC - 1) / KC, nchunk_p = (nchunk + 1) & ~1;
@@ -124,7 +129,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino16_kernel(const ConvKArgs 
     unsigned uoff = lane * 16;
 
     float ur[4][4];         // ring of A operands: position pair P of a chunk in ur[P & 3], requested 3 pairs ahead
-    float bv[2][4][16];     // B operands of two chunks: [set][2 * k-step + block][position] (a transform writes 16 in a row)
+    float bv[2][2 * NB][16];    // B operands of two chunks: [set][NB * k-step + block][position] (a transform writes 16 in a row)
     f32x2 dlo[4], dhi[4];   // the patch being transformed (read from LDS one MFMA group before it is used)
     float px[KC][NJ][2];    // raw halo pairs of the NEXT chunk to stage
 
@@ -162,7 +167,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino16_kernel(const ConvKArgs 
             rp[0] = v0; rp[1] = v1;
         }
     };
-    // B^T d B of the patch of block BK, local channel 4 * KS + lq, out of raw stage st -> bv[SET][2 * KS + BK][f]:
+    // B^T d B of the patch of block BK, local channel 4 * KS + lq, out of raw stage st -> bv[SET][NB * KS + BK][f]:
     // xf_rd requests the patch, xf_math (a couple of MFMAs later) transforms it
     auto xf_rd = [&](int st, auto ks_, auto bk_) {
         constexpr int KS = decltype(ks_)::value, BK = decltype(bk_)::value;
@@ -188,8 +193,8 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino16_kernel(const ConvKArgs 
             const f32x2 sg = {-1.f, 1.f};
             const f32x2 v01 = tl[i] + h00 * sg;                 // (t0 - t2, t1 + t2)
             const f32x2 v23 = th[i] - l11;                      // (t2 - t1, -(t1 - t3)): the pack carries column 3's sign
-            bv[SET][2 * KS + BK][4 * i + 0] = v01[0]; bv[SET][2 * KS + BK][4 * i + 1] = v01[1];
-            bv[SET][2 * KS + BK][4 * i + 2] = v23[0]; bv[SET][2 * KS + BK][4 * i + 3] = v23[1];
+            bv[SET][NB * KS + BK][4 * i + 0] = v01[0]; bv[SET][NB * KS + BK][4 * i + 1] = v01[1];
+            bv[SET][NB * KS + BK][4 * i + 2] = v23[0]; bv[SET][NB * KS + BK][4 * i + 3] = v23[1];
         }
     };
     auto xform = [&](int st, auto set_, auto ks_, auto bk_) { xf_rd(st, ks_, bk_); xf_math(set_, ks_, bk_); };
@@ -209,17 +214,22 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino16_kernel(const ConvKArgs 
         // MFMAs apart.
         auto mf = [&](auto f_, auto ks_, auto bk_) {
             constexpr int F = decltype(f_)::value, KS = decltype(ks_)::value, BK = decltype(bk_)::value;
-            wino16_mfma(acc[F][BK], ur[P & 3][2 * (F & 1) + KS], bv[SET][2 * KS + BK][F]);
+            if constexpr (BK < NB) wino16_mfma(acc[F][BK < NB ? BK : 0], ur[P & 3][2 * (F & 1) + KS], bv[SET][NB * KS + (BK < NB ? BK : 0)][F]);
         };
+        // the patch transform (k-step, block) this position pair carries behind its MFMAs: NB = 2: pairs 4..7 one each;
+        // NB = 1: pairs 4 and 5
+        constexpr int XI = P - 4;
+        constexpr bool XF = P >= 4 && XI < 2 * NB;
+        constexpr int XKS = XF ? (NB == 2 ? XI >> 1 : XI) : 0, XBK = XF ? (NB == 2 ? XI & 1 : 0) : 0;
         mf(IC(2 * P), IC(0), IC(0)); mf(IC(2 * P), IC(0), IC(1));
         if constexpr (P < 4) { x_store(stn, IC(P < 4 ? 2 * P : 0)); x_store(stn, IC(P < 4 ? 2 * P + 1 : 0)); }
-        if constexpr (P >= 4) xf_rd(stn, IC((P - 4) >> 1), IC((P - 4) & 1));
+        if constexpr (XF) xf_rd(stn, IC(XKS), IC(XBK));
         SB();
         mf(IC(2 * P + 1), IC(0), IC(0)); mf(IC(2 * P + 1), IC(0), IC(1));
         if constexpr (P < 4) { x_load(chunk + 2, IC(P < 4 ? 2 * P : 0)); x_load(chunk + 2, IC(P < 4 ? 2 * P + 1 : 0)); }
         SB();
         mf(IC(2 * P), IC(1), IC(0)); mf(IC(2 * P), IC(1), IC(1));
-        if constexpr (P >= 4) xf_math(IC(SET ^ 1), IC((P - 4) >> 1), IC((P - 4) & 1));
+        if constexpr (XF) xf_math(IC(SET ^ 1), IC(XKS), IC(XBK));
         SB();
         mf(IC(2 * P + 1), IC(1), IC(0)); mf(IC(2 * P + 1), IC(1), IC(1));
         // ring slot of pair P + 3 (of this chunk or the next) was last read by pair P - 1
@@ -248,7 +258,8 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino16_kernel(const ConvKArgs 
     __syncthreads();
     x_load(1, IC(0)); x_load(1, IC(1)); x_load(1, IC(2)); x_load(1, IC(3));
     x_load(1, IC(4)); x_load(1, IC(5)); x_load(1, IC(6)); x_load(1, IC(7));
-    xform(0, IC(0), IC(0), IC(0)); xform(0, IC(0), IC(0), IC(1)); xform(0, IC(0), IC(1), IC(0)); xform(0, IC(0), IC(1), IC(1));
+    xform(0, IC(0), IC(0), IC(0)); xform(0, IC(0), IC(1), IC(0));
+    if constexpr (NB == 2) { xform(0, IC(0), IC(0), IC(NB - 1)); xform(0, IC(0), IC(1), IC(NB - 1)); }
     // (whole pairs of chunks: the accumulators must not cross a conditional.  A chunk past the end multiplies the
     // pack's zero slab by patches of the clamped last raw chunk.)
     SB();
@@ -270,7 +281,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino16_kernel(const ConvKArgs 
     const bool sigmoid = a.act == SCM_ACT_SIGMOID;
     const float slope = scm_act_slope(a.act);
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < NB; ++k) {
         const int oy = p00[k] / W;
         const bool row1 = oy + 1 < H;
 #pragma unroll
@@ -369,9 +380,9 @@ int scm_pack_wino16(const float* w, int cin, int cout, int transposed_src, int w
     return SCM_OK;
 }
 
-static inline int w16_plane(int H, int W) {
+static inline int w16_plane(int H, int W, int tiles = W16_TILES) {
     const int tcw = W / 2, trh = (H + 1) / 2;
-    int trows = (W16_TILES % tcw == 0) ? W16_TILES / tcw : (W16_TILES + tcw - 2) / tcw + 1;
+    int trows = (tiles % tcw == 0) ? tiles / tcw : (tiles + tcw - 2) / tcw + 1;
     if (trows > trh) trows = trh;
     return (2 * trows + 2) * (W + 6);
 }
@@ -379,10 +390,10 @@ static inline int w16_plane(int H, int W) {
 // (three pixel pairs per thread and channel at most: 84 x 84 frames -- BASELINE configs[3] -- need 1 080 floats per channel)
 bool scm_wino16_serves(int H, int W) { return H >= 2 && W >= 2 && (W & 1) == 0 && w16_plane(H, W) <= 3 * 512; }
 
-template <int NJ, int PADC>
+template <int NJ, int PADC, int NB = 2>
 static int launch_w16(const ConvKArgs& a, hipStream_t s) {
     const size_t lds = ((size_t)2 * KC * NJ * 512 + 16) * sizeof(float);
-    auto kern = conv3x3_wino16_kernel<NJ, PADC>;
+    auto kern = conv3x3_wino16_kernel<NJ, PADC, NB>;
     static std::atomic<uint64_t> attr_done{0};
     if (int rc = scm_ensure_lds_attr(reinterpret_cast<const void*>(kern), attr_done, 160 * 1024)) return rc;
     hipLaunchKernelGGL(kern, dim3(a.B * a.tiles_per_img), dim3(256), lds, s, a);
@@ -394,9 +405,17 @@ static int launch_w16(const ConvKArgs& a, hipStream_t s) {
 int scm_launch_wino16(const ConvKArgs& k, hipStream_t s) {
     ConvKArgs a = k;
     const int ntiles = ((a.H + 1) / 2) * (a.W / 2);
+    const bool circ = a.pad_mode == SCM_PAD_CIRCULAR;
+    // 64-patch workgroups (one block per wave, two or three workgroups per CU) when their halo rows fit one pixel pair per
+    // thread and the grid is large enough to fill the chip that way; SCM_WINO16_NB2=1: the 128-patch form only (A/B)
+    static const bool nb2_only = getenv("SCM_WINO16_NB2") && atoi(getenv("SCM_WINO16_NB2")) != 0;
+    if (!nb2_only && w16_plane(a.H, a.W, 64) <= 512 && (long)a.B * ((ntiles + 63) / 64) >= 512) {
+        a.tiles_per_img = (ntiles + 63) / 64;
+        a.plane = w16_plane(a.H, a.W, 64);
+        return circ ? launch_w16<1, 1, 1>(a, s) : launch_w16<1, 0, 1>(a, s);
+    }
     a.tiles_per_img = (ntiles + W16_TILES - 1) / W16_TILES;
     a.plane = w16_plane(a.H, a.W);
-    const bool circ = a.pad_mode == SCM_PAD_CIRCULAR;
     if (a.plane <= 512) return circ ? launch_w16<1, 1>(a, s) : launch_w16<1, 0>(a, s);
     if (a.plane <= 1024) return circ ? launch_w16<2, 1>(a, s) : launch_w16<2, 0>(a, s);
     return circ ? launch_w16<3, 1>(a, s) : launch_w16<3, 0>(a, s);
