@@ -583,6 +583,19 @@ def main():
                                                 "2x2 output patch and channel pair instead of 36")
             out["kernels"] = {k: {"launches": v["launches"], "ms_total": round(v["ms"], 3),
                                   "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12} for k, v in summ.items()}
+            heads = {k: summ[k] for k in ("decoder_fused_fwd", "decoder_fused_bwd", "reward_fused_fwd", "reward_fused_bwd")
+                     if k in summ}
+            if heads:
+                # the reward head and the decoder + pixel loss: launched ONCE per iteration over the (horizon - 2) x batch
+                # samples of all unrolled steps (Trainer.step), backward from the hidden maps the forward kept
+                nb = len(range(0, a.steps, 10))
+                per = {k: v["launches"] / float(nb) for k, v in heads.items()}
+                spl = a.batch * (a.horizon - 2) / max(per.values())
+                out["heads"] = {"time_batched": all(abs(v - 1.0) < 1e-9 for v in per.values()),
+                                "samples_per_launch": spl, "kept_hidden_maps": bool(ops.save_hidden),
+                                "us_per_iteration": {k: round(v["ms"] * 1e3 / nb, 1) for k, v in heads.items()},
+                                "us_per_64_samples": {k: round(v["ms"] * 1e3 / nb / (a.batch * (a.horizon - 2) / 64.0), 1)
+                                                      for k, v in heads.items()}}
         if world == 1 and not a.profile_mode and a.precision == "fp32" and a.size <= 64:
             # The same iteration with the 3x3 convolutions' fp32 arithmetic emulated on the bf16 MFMA pipe (exact 3-way
             # bf16 split of both operands, six partial products per product, fp32 accumulation: DESIGN.md section 4e).

@@ -950,9 +950,15 @@ class RewardConvFn(Function):
         n = ctypes.c_size_t()
         L.check(L.lib().scm_reward_fused_workspace(B, H, W, Q, ctypes.byref(n)), "scm_reward_fused_workspace")
         ws = _new(z, max(1, n.value))
+        if kernel_timer is not None:
+            OH, OW = (H - 5) // 2 + 1, (W - 5) // 2 + 1
+            ev = kernel_timer.bracket("reward_fused_bwd", 4.0 * B * 9 * ((H - 2) * (W - 2) * 16 * 32 + OH * OW * 32 * Q))
+            ev[0].record()
         L.check(L.lib().scm_reward_fused_bwd(_p(z), _p(pack), _p(g_o), _p(hid), _p(dz), _p(grads[0]), _p(grads[1]), _p(grads[2]),
                                              _p(grads[3]), _p(ws), B, H, W, Q, 1 if acc else 0, _stream()),
                 "scm_reward_fused_bwd")
+        if kernel_timer is not None:
+            ev[1].record()
         if acc:
             return dz, None, None, None, None, None, None
         return dz, grads[0], grads[1], grads[2], grads[3], None, None
