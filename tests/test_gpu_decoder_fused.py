@@ -182,3 +182,41 @@ def test_wide_frames_keep_the_layer_path_for_the_reward_head():
     z = (torch.rand(1, 16, 20, 84, device="cuda") < 0.5).float()
     assert not rp._fused(z)
     assert rp(z).shape == (1, 1)
+
+
+@pytest.mark.parametrize("B,H,W,C", [(3, 64, 64, 3), (2, 84, 84, 3), (2, 33, 20, 2), (9, 16, 16, 1)])
+def test_kept_hidden_map_gives_bitwise_the_recomputed_gradients(B, H, W, C):
+    """scm_decoder_fused_fwd's h_save / scm_decoder_fused_bwd's h_saved and the reward head's: the backward
+    kernels that LOAD the hidden map the forward kept produce bitwise the gradients of the ones that recompute it from z
+    (same MFMA sequence in the forward and in the recomputation), on single-tile, x-tiled (W > 64), ragged and multi-band
+    shapes."""
+    from scm_gan_amd import models as M, ops
+    rng = np.random.default_rng(5 * H + W)
+    zn = ((rng.random((B, 16, H, W)) < 0.5) * rng.random((B, 16, H, W))).astype(np.float32)
+    tgt = dev((rng.random((B, C, H, W)) < 0.2).astype(np.float32))
+    gl = dev((rng.random(B) + 0.5).astype(np.float32))
+    dec = make_decoder(H + W, C)
+    rp = M.RewardPredictor(16, 2)
+    rp.load_state_dict(WS.to_torch(WS.reward_state(H + W + 1, rewards=2)))
+    assert dec._fused()
+    fused_rp = rp._fused(dev(zn))
+    out = {}
+    old = ops.save_hidden
+    try:
+        for keep in (True, False):
+            ops.save_hidden = keep
+            res = []
+            for net, run in ((dec, lambda z: (dec.forward_loss(z, tgt) * gl).sum()),
+                             (rp, lambda z: (rp(z) * gl[:, None]).sum())):
+                z = dev(zn).requires_grad_(True)
+                for p in net.parameters():
+                    p.grad = None
+                run(z).backward()
+                res.append([z.grad.clone()] + [p.grad.clone() for p in net.parameters()])
+            out[keep] = res
+    finally:
+        ops.save_hidden = old
+    for a, b in zip(out[True], out[False]):
+        for ga, gb in zip(a, b):
+            assert torch.equal(ga, gb)
+    assert fused_rp == (W <= 64 and H >= 5 and W >= 5)
