@@ -287,22 +287,28 @@ def measured_traffic(kernel_name):
     import glob
     kind = "h16" if "h16" in kernel_name else ("x3" if "x3_kernel" in kernel_name else
                                                ("wino" if "wino" in kernel_name else "mfma"))
-    src = {"h16": "conv3x3_h16.hip", "x3": "conv3x3_x3.hip", "mfma": "conv3x3_mfma.hip", "wino": "conv3x3_wino.hip"}[kind]
-    sha = _sha16(os.path.join(ROOT, "scm_gan_amd", "csrc", src))
-    want = {"h16": "conv3x3_h16_kernel<1, 4, 2, 2, 0, 2, 1>" if HALF_STORE else "conv3x3_h16_kernel<1,", "x3": "conv3x3_x3_kernel<2, 2, 0,", "mfma": "conv3x3_mfma_kernel<4, 2, 2, 0,",
-            "wino": "conv3x3_wino_kernel<1, 0, 1, 128>"}[kind]
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_pmc*.json")), reverse=True):
-        try:
-            pmc = json.load(open(f))
-        except Exception:
-            continue
-        if pmc.get("kernel_source_sha16", {}).get(src) != sha:
-            continue
-        for k, v in pmc.get("kernels", {}).items():
-            if want in k and "hbm_traffic_bytes" in v:
-                return {"bytes": v["hbm_traffic_bytes"], "kernel": k, "file": os.path.basename(f),
-                        "kernel_source_sha16": sha, "measured_at_commit": pmc.get("git_commit"),
-                        "mfma_busy": v.get("mfma_utilisation"), "duration_us_median": v.get("duration_us_median")}
+    # (the wide Winograd launches of 64-wide frames run the two-tiles-per-workgroup form, conv3x3_wino_t2.hip; a PMC file
+    # from before it existed -- or SCM_WINO_T2=0 -- holds the one-tile kernel's row)
+    cands = {"h16": [("conv3x3_h16.hip", "conv3x3_h16_kernel<1, 4, 2, 2, 0, 2, 1>" if HALF_STORE else "conv3x3_h16_kernel<1,")],
+             "x3": [("conv3x3_x3.hip", "conv3x3_x3_kernel<2, 2, 0,")], "mfma": [("conv3x3_mfma.hip", "conv3x3_mfma_kernel<4, 2, 2, 0,")],
+             "wino": ([("conv3x3_wino_t2.hip", "conv3x3_wino_t2_kernel<1>")] if os.environ.get("SCM_WINO_T2", "1") not in ("", "0")
+                      and (H, W) == (64, 64) else []) + [("conv3x3_wino.hip", "conv3x3_wino_kernel<1, 0, 1, 128>")]}[kind]
+    for src, want in cands:
+        sha = _sha16(os.path.join(ROOT, "scm_gan_amd", "csrc", src))
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_pmc*.json")), reverse=True):
+            try:
+                pmc = json.load(open(f))
+            except Exception:
+                continue
+            if pmc.get("kernel_source_sha16", {}).get(src) != sha:
+                continue
+            for k, v in pmc.get("kernels", {}).items():
+                if want in k and "hbm_traffic_bytes" in v:
+                    return {"bytes": v["hbm_traffic_bytes"], "kernel": k, "file": os.path.basename(f),
+                            "kernel_source_sha16": sha, "measured_at_commit": pmc.get("git_commit"),
+                            "mfma_busy": v.get("mfma_utilisation"), "duration_us_median": v.get("duration_us_median")}
+        if cands[0][0] == "conv3x3_wino_t2.hip" and src == "conv3x3_wino_t2.hip":
+            return None         # (the two-tile kernel is the one that ran: do not cite the one-tile kernel's counters for it)
     return None
 
 
@@ -334,8 +340,8 @@ def encoder_leg(dev, batch):
     peak = PEAK_F32_MFMA_TFLOPS if ops.compute_precision() == "fp32" else PEAK_F16_MFMA_TFLOPS
     layers, tot_us, tot_issued, tot_alg = [], 0.0, 0.0, 0.0
     pmc_names = {"conv1": ("conv3x3_wino_k16_kernel<1, 0, 0", "conv3x3_wino_k16.hip"),
-                 "conv2": ("conv3x3_wino_kernel<1, 0, 0, 128>", "conv3x3_wino.hip"),
-                 "conv3": ("conv3x3_wino_kernel<1, 0, 0, 128>", "conv3x3_wino.hip"),
+                 "conv2": ("conv3x3_wino_t2_kernel<0>", "conv3x3_wino_t2.hip"),
+                 "conv3": ("conv3x3_wino_t2_kernel<0>", "conv3x3_wino_t2.hip"),
                  "conv4": ("conv3x3_wino16_kernel<2, 0", "conv3x3_wino16.hip")}
     for i, nm in enumerate(names):
         recs = timer.records[i::per]

@@ -57,3 +57,7 @@ __device__ __forceinline__ void scm_xcd_tile_map(int B, int tiles_per_img, int& 
         cg = blockIdx.y;
     }
 }
+
+// two tiles per workgroup (conv3x3_wino_t2.hip): the hot 128-channel instantiation on 64-wide frames
+bool scm_wino_t2_serves(const ConvKArgs& k);
+int scm_launch_wino_t2(const ConvKArgs& k, int groups, hipStream_t s);

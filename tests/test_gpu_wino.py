@@ -390,3 +390,54 @@ def test_producer_side_gating_equals_consumer_side():
     assert len(res[True]) == len(res[False]) >= 20
     for p, q in zip(res[True], res[False]):
         assert float((p - q).abs().max()) <= 2e-6 * max(1e-6, float(q.abs().max())), float((p - q).abs().max())
+
+
+@pytest.mark.parametrize("B,c1,c2,cout,H,pad,mode", [
+    (3, 128, 0, 128, 64, 1, "forward"), (2, 128, 128, 128, 64, 1, "forward"), (2, 128, 0, 256, 64, 0, "forward"),
+    (2, 64, 0, 128, 8, 1, "forward"), (2, 128, 0, 256, 64, 1, "gated_dgrad"), (3, 128, 0, 128, 12, 0, "gated_dgrad_acc")])
+def test_two_tiles_per_workgroup_is_bitwise_the_one_tile_kernel(K, B, c1, c2, cout, H, pad, mode, monkeypatch):
+    """conv3x3_wino_t2.hip (64-wide frames, H % 4 == 0, 128-channel groups, ungated input: every wide launch of the
+    transition / encoder at 64 x 64): a workgroup takes two vertically adjacent tiles, the second tile's first rows
+    requested before the first tile's epilogue.  Same pack, same order of operations per output: bitwise the results of
+    conv3x3_wino_kernel<1, 0, PADC, 128> (SCM_WINO_T2=0) -- forward with bias / scale / per-sample bias and the 1-bit gate
+    it writes, two input tensors, split outputs; input gradients with the destination's gate words, with accumulate;
+    wrapped (circular) and zero-padded first / last tiles."""
+    from scm_gan_amd import _lib as L
+    W = 64
+    torch.manual_seed(H + cout)
+    x1 = torch.randn(B, c1, H, W, device="cuda")
+    x2 = torch.randn(B, c2, H, W, device="cuda") if c2 else None
+    w = torch.randn(cout, c1 + c2, 3, 3, device="cuda") * 0.05
+    fp, _ = K.pack(w, 1)
+    bias = torch.randn(cout, device="cuda")
+    sbias = torch.randn(B, cout, device="cuda")
+    scale = torch.full((1,), 0.7, device="cuda")
+    co1 = 128 if cout == 256 else cout
+    a1, a2 = torch.randn(B, co1, H, W, device="cuda"), (torch.randn(B, cout - co1, H, W, device="cuda") if co1 < cout else None)
+    m1, m2 = mask_words(a1), (mask_words(a2) if a2 is not None else None)
+
+    def run(t2):
+        monkeypatch.setenv("SCM_WINO_T2", "1" if t2 else "0")
+        if mode == "forward":
+            mask = torch.zeros(B, cout // 32, H, W, device="cuda", dtype=torch.int32)
+            y1, y2 = K.conv(1, x1, x2, fp, cout, pad, 1, bias=bias, sbias=sbias, scale=scale, co1=co1, mask_out=mask)
+            return [y1, y2, mask]
+        acc = mode.endswith("acc")
+        y1 = torch.full((B, co1, H, W), 0.25, device="cuda") if acc else torch.empty(B, co1, H, W, device="cuda")
+        y2 = torch.empty(B, cout - co1, H, W, device="cuda") if co1 < cout else None
+        d = L.ConvDesc(K.P(x1), None, c1, 0, None, None, 0, K.P(fp), cout, K.P(scale), None, None, K.P(y1), K.P(y2), co1, B, H, W,
+                       pad, 0, None, None, 1 if acc else 0, K.P(m1), K.P(m2))
+        L.check(K.lib.scm_conv3x3_wino(ctypes.byref(d), K.S()), "conv")
+        return [y1, y2]
+    two, one = run(True), run(False)
+    for t, o in zip(two, one):
+        assert (t is None) == (o is None)
+        if t is not None:
+            assert torch.equal(t, o)
+    # (and the float64 reference, so that the pair is not only self-consistent)
+    if mode == "forward":
+        xx = x1 if x2 is None else torch.cat([x1, x2], 1)
+        ref = ref_conv(xx.double(), w.double() * 0.7, None, pad, 0) + (bias.double().view(1, -1, 1, 1) + sbias.double().view(B, -1, 1, 1))
+        ref = F.leaky_relu(ref)
+        got = two[0] if two[1] is None else torch.cat([two[0], two[1]], 1)
+        assert float((got.double() - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))

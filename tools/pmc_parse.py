@@ -37,7 +37,7 @@ for k, c in vals.items():
     out[k] = e
 here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sha = {}
-for f in ('conv3x3_wino.hip', 'conv3x3_wgrad_wino.hip', 'conv3x3_wino16.hip', 'conv3x3_wgrad_wino16.hip', 'conv3x3_wino_k16.hip', 'conv3x3_mfma.hip', 'conv3x3_h16.hip', 'conv3x3_x3.hip', 'conv3x3_wgrad.hip', 'conv3x3_wgrad_h16.hip', 'conv3x3_wgrad_x3.hip',
+for f in ('conv3x3_wino.hip', 'conv3x3_wino_t2.hip', 'conv3x3_wgrad_wino.hip', 'conv3x3_wino16.hip', 'conv3x3_wgrad_wino16.hip', 'conv3x3_wino_k16.hip', 'conv3x3_mfma.hip', 'conv3x3_h16.hip', 'conv3x3_x3.hip', 'conv3x3_wgrad.hip', 'conv3x3_wgrad_h16.hip', 'conv3x3_wgrad_x3.hip',
           'decoder_fused.hip', 'reward_fused.hip', 'sn.hip'):
     try:
         sha[f] = hashlib.sha256(open(os.path.join(here, 'scm_gan_amd', 'csrc', f), 'rb').read()).hexdigest()[:16]
