@@ -555,8 +555,10 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_t2_kernel(const ConvKArgs
 bool scm_wino_t2_serves(const ConvKArgs& k) {
     const char* e = getenv("SCM_WINO_T2");          // (read per launch: SCM_WINO_T2=0 -> one tile per workgroup, the A/B; tests switch it)
     const int on = e ? atoi(e) : 1;
+    // (... and a grid that still fills the chip twice when every workgroup takes two tiles: at batch 8 the one-tile form's
+    // 256 workgroups are one round on 256 CUs, 128 two-tile workgroups would leave half of them idle)
     return on && k.W == 64 && (k.H & 3) == 0 && k.gate_act == 0 && k.act != SCM_ACT_SIGMOID && (k.cout & 127) == 0 &&
-           (k.co1 & 31) == 0;
+           (k.co1 & 31) == 0 && (long)k.B * (k.H / 4) * (k.cout / 128) >= 512;
 }
 
 template <int PADC>

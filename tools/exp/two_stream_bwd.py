@@ -1,5 +1,5 @@
 """Would running the weight-gradient kernel of a layer on a second stream, next to the input-gradient conv of
-the same layer, hide the launch ramps?  Chain of 16 (dgrad, wgrad) pairs at 128 -> 128, B=64, 64x64."""
+the same layer, hide the launch ramps?  Chain of 16 (dgrad, wgrad) pairs at 128 -> 128, B=64, 64x64 (the default Winograd kernels)."""
 import ctypes, sys, torch
 sys.path.insert(0, '.')
 from scm_gan_amd import _lib as L, ops
@@ -17,11 +17,12 @@ part = [torch.empty(pf.value, device='cuda') for _ in range(2)]; cws = [torch.em
 dw = torch.empty_like(w); db = torch.empty(C, device='cuda')
 side = torch.cuda.Stream()
 def dgrad(src, dst):
-    d = L.ConvDesc(P(src), None, C, 0, P(y), None, ops.ACT_LRELU, P(dp), C, None, None, None, P(dst), None, C, B, H, W, 1, 0, None, P(mask), 0)
-    L.check(lib.scm_conv3x3(ctypes.byref(d), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), 'dgrad')
+    # (as the training step launches it: ungated input, the destination's gate words applied to what it writes)
+    d = L.ConvDesc(P(src), None, C, 0, None, None, 0, P(dp), C, None, None, None, P(dst), None, C, B, H, W, 1, 0, None, None, 0, P(mask), None)
+    L.check(lib.scm_conv3x3_wino(ctypes.byref(d), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), 'dgrad')
 def wgrad(g, k):
-    d = L.WgradDesc(P(x), None, C, 0, P(g), P(y), ops.ACT_LRELU, C, P(dw), P(db), None, P(part[k]), P(cws[k]), B, H, W, 1, 0, 0, 0, 0, None, None, P(mask))
-    L.check(lib.scm_conv3x3_wgrad(ctypes.byref(d), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), 'wgrad')
+    d = L.WgradDesc(P(x), None, C, 0, P(g), None, 0, C, P(dw), P(db), None, P(part[k]), P(cws[k]), B, H, W, 1, 0, 0, 0, 0, None, None, None)
+    L.check(lib.scm_conv3x3_wgrad_wino(ctypes.byref(d), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), 'wgrad')
 def chain(two):
     main = torch.cuda.current_stream()
     for i in range(16):
