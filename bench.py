@@ -277,6 +277,7 @@ def measured_pmc(kernel_substr, source_file, need="hbm_traffic_bytes"):
 
 
 HALF_STORE = False          # set in main(): the 16-bit mode with half-stored activations (its forward is the XH = 1 instantiation)
+WINO_T2 = False             # set in main(): the wide Winograd launches run conv3x3_wino_t2.hip (scm_wino_t2_serves' conditions)
 
 
 def measured_traffic(kernel_name):
@@ -291,8 +292,8 @@ def measured_traffic(kernel_name):
     # from before it existed -- or SCM_WINO_T2=0 -- holds the one-tile kernel's row)
     cands = {"h16": [("conv3x3_h16.hip", "conv3x3_h16_kernel<1, 4, 2, 2, 0, 2, 1>" if HALF_STORE else "conv3x3_h16_kernel<1,")],
              "x3": [("conv3x3_x3.hip", "conv3x3_x3_kernel<2, 2, 0,")], "mfma": [("conv3x3_mfma.hip", "conv3x3_mfma_kernel<4, 2, 2, 0,")],
-             "wino": ([("conv3x3_wino_t2.hip", "conv3x3_wino_t2_kernel<1>")] if os.environ.get("SCM_WINO_T2", "1") not in ("", "0")
-                      and (H, W) == (64, 64) else []) + [("conv3x3_wino.hip", "conv3x3_wino_kernel<1, 0, 1, 128>")]}[kind]
+             "wino": ([("conv3x3_wino_t2.hip", "conv3x3_wino_t2_kernel<1>")] if WINO_T2 else [])
+                     + [("conv3x3_wino.hip", "conv3x3_wino_kernel<1, 0, 1, 128>")]}[kind]
     for src, want in cands:
         sha = _sha16(os.path.join(ROOT, "scm_gan_amd", "csrc", src))
         for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_pmc*.json")), reverse=True):
@@ -446,8 +447,10 @@ def main():
     from scm_gan_amd.datasource import SyntheticDatasource
     ops.set_compute_precision(a.precision)
     ops.set_half_store(not a.no_half_store)
-    global HALF_STORE
+    global HALF_STORE, WINO_T2
     HALF_STORE = a.precision == "fp16" and not a.no_half_store
+    WINO_T2 = (os.environ.get("SCM_WINO_T2", "1") not in ("", "0") and (H, W) == (64, 64) and a.batch * (H // 4) >= 512
+               and a.precision == "fp32" and a.conv_algo != "direct")
     if a.conv_algo:
         ops.set_conv_algo(a.conv_algo)
     opts = M.parser.parse_args(["--train-iters", str(a.steps + a.warmup), "--horizon-min", str(a.horizon),
@@ -584,6 +587,10 @@ def main():
                 out["roofline"]["traffic_algorithmic_bytes"] = alg_bytes
                 out["roofline"]["traffic_ratio"] = tr_info["bytes"] / alg_bytes
                 out["roofline"]["mfma_busy_pmc"] = tr_info.get("mfma_busy")
+            if wino and WINO_T2:
+                out["roofline"]["kernel_form"] = ("conv3x3_wino_t2_kernel: two vertically adjacent 128-channel x 32-patch tiles per "
+                                                  "workgroup (the family's launches with <= 16 channels on one side have their own "
+                                                  "buckets)")
             if wino:
                 out["roofline"]["algorithm"] = ("Winograd F(2x2,3x3), fp32 operands / fp32 accumulate: 16 MFMA products per "
                                                 "2x2 output patch and channel pair instead of 36")

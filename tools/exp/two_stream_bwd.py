@@ -10,7 +10,7 @@ x = torch.randn(B, C, H, W, device='cuda'); w = torch.randn(C, C, 3, 3, device='
 gy = [torch.randn(B, C, H, W, device='cuda') * 1e-4 for _ in range(2)]
 y = torch.randn(B, C, H, W, device='cuda')
 mask = torch.zeros(B, C // 32, H, W, device='cuda', dtype=torch.int32)
-fp, dp, _, _ = ops.pack_conv3x3(w, C, C)
+fp, dp = ops.pack_conv3x3(w, C, C)[:2]
 pf, cf = ctypes.c_size_t(), ctypes.c_size_t()
 lib.scm_conv3x3_wgrad_workspace(B, H, W, C, C, ctypes.byref(pf), ctypes.byref(cf))
 part = [torch.empty(pf.value, device='cuda') for _ in range(2)]; cws = [torch.empty(cf.value, device='cuda') for _ in range(2)]
