@@ -1,8 +1,8 @@
 // Two tiles per workgroup: the hot instantiation of conv3x3_wino.hip (128 output channels x 32 patches per tile, one raw
 // pixel pair per thread, ungated input, the fast epilogue) for frames whose patch rows are 32 patches wide (W = 64), with
-// every workgroup taking TWO vertically adjacent tiles of an image one after the other.  What that buys (DESIGN.md 4i:
+// every workgroup taking TWO tiles of an image (half an image apart) one after the other.  What that buys (DESIGN.md 4i:
 // setup 1.8 k + prologue 2.5 k + gap 0.5 k ticks per 84 k-tick tile): one kernel-argument wait, one tile map and one set of
-// staging maps per pair -- the second tile's maps are the first's moved down two image rows -- and the second tile's first
+// staging maps per pair -- the second tile's maps are the first's moved down half an image -- and the second tile's first
 // rows and filters are requested BEFORE the first tile's epilogue, so their latency passes under its 6.5 k ticks.
 // Same pack, same arithmetic order per output as conv3x3_wino_kernel<1, 0, PADC, 128>: bitwise the same results.
 // Reference: /root/reference/models.py:76-102 (Transition conv2..conv5), :145-155 (Encoder conv2 / conv3) and their
@@ -79,7 +79,12 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_t2_kernel(const ConvKArgs
     // (host: TCW == 32 -- a tile is one patch row -- H % 4 == 0, a.tiles_per_img = TILE PAIRS per image)
     int b, wtp, cg;
     scm_xcd_tile_map(a.B, a.tiles_per_img, b, wtp, cg);
-    const int k0 = 2 * wtp;                           // first tile (= patch row) of this workgroup's pair
+    // The pair: tile wtp and the tile HALF AN IMAGE below it.  Workgroups that run at the same time on an XCD then work on
+    // vertically adjacent tiles (both their first, later both their second) and meet in its L2 for the two halo rows they
+    // share, as in the one-tile kernel; with (2 wtp, 2 wtp + 1) the neighbour's rows were requested 80 k ticks apart: PMC
+    // 477 instead of 358 MB of HBM traffic per launch.
+    const int k0 = wtp;                               // first tile (= patch row) of this workgroup's pair
+    const int kstep = a.tiles_per_img;                // ... and the second one: k0 + (tile pairs per image)
     (void)ntiles;
     const int HPR = (W + 4) >> 1;                     // pairs per raw row
     const int npair = 4 * HPR;                        // a tile's four raw rows
@@ -109,7 +114,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_t2_kernel(const ConvKArgs
     const int sq_r = tid / HPR, sq_c = tid - sq_r * HPR;        // this thread's pair: raw row, pair column (one division per pair of tiles)
     const bool sq_live = tid < npair;
     rawi[0] = sq_live ? sq_r * ROWPL + 2 * sq_c + 1 : 0;        // (slots 0, 1 are never read)
-    // staging map of tile k: the second tile's is the first's moved down two image rows (no division, no tile map)
+    // staging map of tile k: the second tile's is the first's moved down half an image (no division, no tile map)
     auto set_tile = [&](int k) __attribute__((always_inline)) {
         int g = 0;
         okmask = 0u;
@@ -536,10 +541,10 @@ __global__ void __launch_bounds__(256, 1) conv3x3_wino_t2_kernel(const ConvKArgs
     // second tile: its staging map and its first requests, THEN the first tile's epilogue
     const int p00_first = p00;
     const unsigned gw_first[4] = {gwl[0], gwl[1], gwl[2], gwl[3]};
-    set_tile(k0 + 1);
+    set_tile(k0 + kstep);
     prologue_issue();
     epilogue(p00_first, gw_first);
-    p00 += 2 * W;
+    p00 += 2 * W * kstep;
     gw_load();
     prologue_finish();
     kloop();
