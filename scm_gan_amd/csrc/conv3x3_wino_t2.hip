@@ -562,8 +562,12 @@ bool scm_wino_t2_serves(const ConvKArgs& k) {
     const int on = e ? atoi(e) : 1;
     // (... and a grid that still fills the chip twice when every workgroup takes two tiles: at batch 8 the one-tile form's
     // 256 workgroups are one round on 256 CUs, 128 two-tile workgroups would leave half of them idle)
+    // (... and whole rounds: one workgroup per CU on MI355X's 256 CUs, 164.4 k ticks per pair against 83.8 k per tile -- at the
+    // eval batch of 100, 1 600 pairs are 7 rounds where 3 200 tiles are 12.5: the one-tile form wins by 5 %, measured 1.7 %)
+    const long wg2 = (long)k.B * (k.H / 4) * (k.cout / 128), wg1 = 2 * wg2;
+    const long t2 = ((wg2 + 255) / 256) * 1644, t1 = ((wg1 + 255) / 256) * 838;
     return on && k.W == 64 && (k.H & 3) == 0 && k.gate_act == 0 && k.act != SCM_ACT_SIGMOID && (k.cout & 127) == 0 &&
-           (k.co1 & 31) == 0 && (long)k.B * (k.H / 4) * (k.cout / 128) >= 512;
+           (k.co1 & 31) == 0 && wg2 >= 512 && t2 <= t1;
 }
 
 template <int PADC>
